@@ -1,0 +1,421 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference.
+
+Run in the build container only (it needs /root/reference and /opt/conda/lib/libmkl_rt.so):
+
+    LD_LIBRARY_PATH=/opt/conda/lib python tests/golden/make_golden.py
+
+Every array written here is either a seeded synthetic input or the output of the reference's own
+functions called on it (superdsm.preprocess / objects / dsm / atoms / minsetcover / maxsetpack /
+globalenergymin / automation).  ``cvxopt`` is absent, so solver *iterates* are not pinned; tight
+optima are obtained by driving the reference's ``Energy`` (value, gradient, Hessian) with SciPy's
+``trust-exact`` until the gradient vanishes -- psi is convex, so the optimum is solver-independent.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import scipy.ndimage as ndi
+import scipy.optimize
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _refshim  # noqa: E402
+
+_refshim.install()
+
+import superdsm.atoms  # noqa: E402
+import superdsm.automation  # noqa: E402
+import superdsm.config  # noqa: E402
+import superdsm.dsm as rdsm  # noqa: E402
+import superdsm.globalenergymin as rgem  # noqa: E402
+import superdsm.image as rimage  # noqa: E402
+import superdsm.maxsetpack  # noqa: E402
+import superdsm.minsetcover as rmsc  # noqa: E402
+import superdsm.objects as robjects  # noqa: E402
+import superdsm.pipeline  # noqa: E402
+import superdsm.preprocess  # noqa: E402
+from superdsm._aux import uplift_smooth_matrix  # noqa: E402
+
+from superdsm_amd import synth  # noqa: E402
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'{name}.npz: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def pack(mask):
+    return np.packbits(np.asarray(mask, bool).reshape(-1)), np.asarray(mask.shape, np.int64)
+
+
+# ----------------------------------------------------------------------------------------------
+# preprocessing (superdsm/preprocess.py:39-68)
+# ----------------------------------------------------------------------------------------------
+
+def gen_preprocess():
+    stage = superdsm.preprocess.Preprocessing()
+    cases = {
+        'a': dict(shape=(120, 150), n=6, radius=9, seed=11, cfg=dict(sigma2=10)),
+        'b': dict(shape=(90, 70), n=4, radius=7, seed=12, cfg=dict(sigma2=4.5, sigma1=1.0, lower_clip_mean=True)),
+        'c': dict(shape=(64, 96), n=3, radius=8, seed=13, cfg=dict(sigma2=6, offset_clip=float('inf'))),
+        'd': dict(shape=(50, 40), n=2, radius=6, seed=14, cfg=dict(sigma2=20, offset_clip=1.5)),  # taps > image: repeated reflection
+    }
+    for key, c in cases.items():
+        layout = synth.random_layout(c['shape'], c['n'], c['radius'], c['seed'])
+        g = synth.render_image(c['shape'], layout, c['seed'])
+        y = stage.process(dict(g_raw=g), cfg=superdsm.config.Config(dict(c['cfg'])), out=None, log_root_dir=None)['y']
+        save(f'preprocess_{key}', g_raw=g, y=y, cfg=json.dumps(c['cfg']))
+
+
+# ----------------------------------------------------------------------------------------------
+# a small synthetic scene shared by the region / energy / optimum fixtures
+# ----------------------------------------------------------------------------------------------
+
+def make_scene(shape, n, radius, seed, sigma2):
+    layout = synth.random_layout(shape, n, radius, seed, min_sep=1.4)
+    g = synth.render_image(shape, layout, seed)
+    stage = superdsm.preprocess.Preprocessing()
+    y = stage.process(dict(g_raw=g), cfg=superdsm.config.Config(dict(sigma2=sigma2)), out=None, log_root_dir=None)['y']
+    atoms, clusters, seeds = synth.make_atoms(y, layout, seed)
+    return g, y, atoms, clusters, seeds
+
+
+def gen_region(scene):
+    g, y, atoms, clusters, seeds = scene
+    rng = np.random.default_rng(5)
+    y_mask = np.ones(y.shape, bool)
+    y_mask[:, :7] = False
+    y_mask[rng.integers(0, y.shape[0], 40), rng.integers(0, y.shape[1], 40)] = False
+    yimg = rimage.Image.create_from_array(y, normalize=False, mask=y_mask)
+    fps = [[1], [2, 3], list(range(1, min(6, atoms.max()) + 1))]
+    out = {}
+    for i, fp in enumerate(fps):
+        for margin in (3, 8):
+            obj = robjects.Object()
+            obj.footprint = set(fp)
+            region = obj.get_cvxprog_region(yimg, atoms, margin)
+            out[f'fp{i}_m{margin}'] = np.packbits(region.mask.reshape(-1))
+            out[f'fp{i}'] = np.asarray(fp)
+    edt_ok8 = ndi.distance_transform_edt(y <= 0) <= 8
+    save('region', y=y, y_mask=np.packbits(y_mask.reshape(-1)), atoms=atoms.astype(np.int32),
+         shape=np.asarray(y.shape), edt_le_8=np.packbits(edt_ok8.reshape(-1)), **out)
+
+
+# ----------------------------------------------------------------------------------------------
+# G~ : sub-sample grid + masked smooth matrix (superdsm/dsm.py:137-237)
+# ----------------------------------------------------------------------------------------------
+
+def blob(shape, centre, axes, angle=0.3):
+    rr, cc = np.mgrid[:shape[0], :shape[1]]
+    ca, sa = np.cos(angle), np.sin(angle)
+    dr, dc = rr - centre[0], cc - centre[1]
+    u = (ca * dr + sa * dc) / axes[0]
+    v = (-sa * dr + ca * dc) / axes[1]
+    return u * u + v * v <= 1
+
+
+def gen_smoothmat():
+    cases = {}
+    cases['blob'] = (blob((60, 70), (28, 33), (24, 19)), 4, 2, 8)
+    two = blob((90, 110), (25, 30), (20, 16)) | blob((90, 110), (60, 80), (22, 18), -0.5)
+    two[40:44, :] = False
+    two[:, 52:58] = False
+    cases['two_blobs_gaps'] = (two, 4, 2, 8)           # empty rows/cols inside the bbox are deleted
+    cases['too_small'] = (blob((30, 30), (12, 12), (7, 9)), 4, 2, 8)   # <= kernel // 2 -> null matrix
+    holes = blob((64, 64), (31, 31), (27, 25))
+    ncr = holes[np.where(holes.any(axis=1))[0], :][:, np.where(holes.any(axis=0))[0]]
+    off_r, off_c = np.where(holes.any(axis=1))[0][0], np.where(holes.any(axis=0))[0][0]
+    for i in range(0, ncr.shape[0], 8):
+        for j in range(0, ncr.shape[1], 8):
+            holes[off_r + i, off_c + j] = False
+    assert holes.any(axis=1)[off_r:off_r + ncr.shape[0]].all() and holes.any(axis=0)[off_c:off_c + ncr.shape[1]].all()
+    cases['no_regular_grid_point'] = (holes, 4, 2, 8)  # greedy loop starts from an empty grid
+    cases['dense_grid_m_gt_128'] = (blob((44, 48), (21, 23), (19, 21)), 1, 2, 2)   # M > 128: numpy pairwise split
+    ell = np.zeros((80, 80), bool)
+    ell[5:75, 8:30] = True
+    ell[55:75, 8:72] = True
+    cases['l_shape'] = (ell, 4, 2, 8)
+    cases['gowt1_like'] = (blob((130, 120), (64, 58), (55, 48), 0.9), 8, 2, 16)
+    cases['odd_params'] = (blob((70, 64), (33, 30), (30, 26), 1.1), 3, 2, 5)
+    for key, (mask, sigma, mult, sub) in cases.items():
+        with quiet():
+            fac = rdsm.SmoothMatrixFactory(sigma, mult, sub, None, 'float32')
+            mat = fac.get(mask)
+            cm = mask[np.where(mask.any(axis=1))[0], :]
+            cm = cm[:, np.where(cm.any(axis=0))[0]]
+            psf = rdsm._create_gaussian_kernel(sigma, shape_multiplier=mult).astype('float32')
+            if mat.shape[1] > 0:
+                grid = rdsm._create_subsample_grid(cm, sub)
+            else:
+                grid = np.zeros(cm.shape, bool)
+        mat.sort_indices()
+        mbits, mshape = pack(mask)
+        gbits, gshape = pack(grid)
+        save(f'smoothmat_{key}', mask=mbits, mask_shape=mshape, grid=gbits, grid_shape=gshape,
+             params=np.asarray([sigma, mult, sub], float), psf=psf,
+             data=mat.data, indices=mat.indices.astype(np.int32), indptr=mat.indptr.astype(np.int64),
+             shape=np.asarray(mat.shape, np.int64))
+
+
+# ----------------------------------------------------------------------------------------------
+# Energy value / gradient / Hessian (superdsm/dsm.py:253-385) and tight optima + mask tail
+# ----------------------------------------------------------------------------------------------
+
+DSM_CFG = dict(smooth_amount=4, smooth_subsample=8, gaussian_shape_multiplier=2, epsilon=1.0, alpha=0.033,
+               scale=1000, background_margin=8)
+
+
+def full_hessian(J, p):
+    H = J.hessian(p)
+    H = H.toarray() if hasattr(H, 'toarray') else np.asarray(H)
+    return H
+
+
+def sym(H):
+    return np.tril(H) + np.tril(H, -1).T
+
+
+def make_energy(yimg, atoms, fp, cfg, deform=True):
+    obj = robjects.Object()
+    obj.footprint = set(fp)
+    region = obj.get_cvxprog_region(yimg, atoms, cfg['background_margin'])
+    with quiet():
+        fac = rdsm.SmoothMatrixFactory(cfg['smooth_amount'], cfg['gaussian_shape_multiplier'], cfg['smooth_subsample'], None, 'float32') \
+            if deform else rdsm.SmoothMatrixFactory.NULL_FACTORY
+        J = rdsm.Energy(region, cfg['epsilon'], cfg['alpha'], fac)
+    return region, J
+
+
+def gen_energy(scene):
+    g, y, atoms, clusters, seeds = scene
+    yimg = rimage.Image.create_from_array(y, normalize=False, mask=np.ones(y.shape, bool))
+    rng = np.random.default_rng(7)
+    out = dict(y=y, atoms=atoms.astype(np.int32), cfg=json.dumps(DSM_CFG))
+    fps = [[1], [2, 3]]
+    k = 0
+    for fp in fps:
+        for deform in (False, True):
+            for alpha in ((DSM_CFG['alpha'],) if not deform else (DSM_CFG['alpha'], 0.0)):
+                cfg = dict(DSM_CFG, alpha=alpha)
+                region, J = make_energy(yimg, atoms, fp, cfg, deform)
+                M = J.smooth_mat.shape[1]
+                init = robjects._estimate_initialization(region).array
+                for scale_p, xi_amp in ((1.0, 0.3), (0.05, 2.0), (3e3, 30.0)):   # the last one exercises the exp() guard
+                    p = np.concatenate([init * scale_p * (1 + 0.2 * rng.standard_normal(6)), xi_amp * rng.standard_normal(M)])
+                    with quiet():
+                        val, grad, H = J(p), J.grad(p), full_hessian(J, p)
+                    out[f'c{k}_fp'] = np.asarray(fp)
+                    out[f'c{k}_deform'] = np.asarray(int(deform))
+                    out[f'c{k}_alpha'] = np.asarray(alpha)
+                    out[f'c{k}_params'] = p
+                    out[f'c{k}_value'] = np.asarray(val)
+                    out[f'c{k}_grad'] = np.asarray(grad)
+                    out[f'c{k}_hessian_lower'] = np.tril(H)
+                    out[f'c{k}_n_guarded'] = np.asarray(int(np.isnan(J.h).sum()))
+                    k += 1
+    out['n_cases'] = np.asarray(k)
+    save('energy', **out)
+
+
+def tight_minimum(J, x0, scale):
+    fun = lambda p: scale * J(p)
+    jac = lambda p: scale * np.asarray(J.grad(p)).reshape(-1)
+    hess = lambda p: scale * sym(full_hessian(J, p))
+    with quiet():
+        res = scipy.optimize.minimize(fun, x0, jac=jac, hess=hess, method='trust-exact', options=dict(gtol=1e-10, maxiter=2000))
+        # polish with plain Newton steps (trust-exact stops on gtol of the scaled problem)
+        x = res.x
+        for _ in range(5):
+            gvec = jac(x)
+            Hm = hess(x)
+            try:
+                step = np.linalg.solve(Hm, -gvec)
+            except np.linalg.LinAlgError:
+                break
+            if fun(x + step) <= fun(x):
+                x = x + step
+        gnorm = np.abs(jac(x)).max()
+    return x, J(x), gnorm
+
+
+def gen_optimum(scene, tag, cfg):
+    g, y, atoms, clusters, seeds = scene
+    yimg = rimage.Image.create_from_array(y, normalize=False, mask=np.ones(y.shape, bool))
+    x_map = yimg.get_map(normalized=False, pad=1)
+    adj = superdsm.atoms.AtomAdjacencyGraph(atoms, clusters, y > 0, seeds, out='muted')
+    cands = synth.enumerate_candidates(adj, max_size=2)
+    # keep it small: the first few atoms, a few unions, one universe
+    picks = [c for c in cands if len(c) == 1][:4] + [c for c in cands if len(c) == 2][:3] + [c for c in cands if len(c) > 2][:1]
+    out = dict(y=y, atoms=atoms.astype(np.int32), clusters=clusters.astype(np.int32), seeds=np.asarray(seeds),
+               cfg=json.dumps(cfg), n_cases=np.asarray(len(picks)))
+    for k, fp in enumerate(picks):
+        region, J_ell = make_energy(yimg, atoms, fp, cfg, deform=False)
+        _, J = make_energy(yimg, atoms, fp, cfg, deform=True)
+        N = int(region.mask.sum())
+        scale = cfg['scale'] / N
+        x_ell, v_ell, g_ell = tight_minimum(J_ell, np.zeros(6), scale)
+        M = J.smooth_mat.shape[1]
+        x_dsm, v_dsm, g_dsm = tight_minimum(J, np.concatenate([x_ell, np.zeros(M)]), scale)
+        # mask tail exactly as the reference does it (superdsm/objects.py:198-209)
+        result = rdsm.DeformableShapeModel(x_dsm)
+        with quiet():
+            padded_mask = np.pad(region.mask, 1)
+            smooth_mat = uplift_smooth_matrix(J.smooth_mat, padded_mask)
+            padded_fg = (result.map_to_image_pixels(yimg, region, pad=1).s(x_map, smooth_mat) > 0)
+        fg = padded_fg[1:-1, 1:-1]
+        if fg.any():
+            fg = np.logical_and(region.mask, fg)
+            off, frag = robjects.extract_foreground_fragment(fg)
+        else:
+            off, frag = np.zeros(2, int), np.zeros((1, 1), bool)
+        on_boundary = bool(padded_fg[0].any() or padded_fg[-1].any() or padded_fg[:, 0].any() or padded_fg[:, -1].any())
+        init = robjects._estimate_initialization(region).array
+        print(f'  {tag} cand {k} fp={fp} N={N} M={M} psi_ell={v_ell:.6f} (|g|={g_ell:.1e}) psi_dsm={v_dsm:.6f} (|g|={g_dsm:.1e}) frag={frag.shape} boundary={on_boundary}')
+        out[f'c{k}_fp'] = np.asarray(fp)
+        out[f'c{k}_N'] = np.asarray(N)
+        out[f'c{k}_M'] = np.asarray(M)
+        out[f'c{k}_region'] = np.packbits(region.mask.reshape(-1))
+        out[f'c{k}_x_ell'] = x_ell
+        out[f'c{k}_psi_ell'] = np.asarray(v_ell)
+        out[f'c{k}_gnorm_ell'] = np.asarray(g_ell)
+        out[f'c{k}_x_dsm'] = x_dsm
+        out[f'c{k}_psi_dsm'] = np.asarray(v_dsm)
+        out[f'c{k}_gnorm_dsm'] = np.asarray(g_dsm)
+        out[f'c{k}_moment_init'] = init
+        out[f'c{k}_psi_moment_init'] = np.asarray(J_ell(init))
+        out[f'c{k}_fg_offset'] = np.asarray(off)
+        out[f'c{k}_fg_fragment'] = np.packbits(frag.reshape(-1))
+        out[f'c{k}_fg_shape'] = np.asarray(frag.shape)
+        out[f'c{k}_on_boundary'] = np.asarray(int(on_boundary))
+    save(f'optimum_{tag}', **out)
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration (superdsm/automation.py:71-102), adjacency, set cover, generation logic
+# ----------------------------------------------------------------------------------------------
+
+class _StubStage(superdsm.pipeline.Stage):
+    ENABLED_BY_DEFAULT = True
+
+
+def gen_config():
+    from superdsm.preprocess import Preprocessing
+    from superdsm.dsmcfg import DSM_Config
+    from superdsm.globalenergymin import GlobalEnergyMinimization
+    pipeline = superdsm.pipeline.Pipeline()
+    for st in (Preprocessing(), DSM_Config(), GlobalEnergyMinimization()):
+        pipeline.append(st)
+    out = {}
+    tasks = {
+        'bbbc039': {'AF_scale': 10, 'dsm': {'AF_alpha': 0.00033}, 'global-energy-minimization': {'AF_beta': 1.5}},
+        'scale40_defaults': {'AF_scale': 40},
+        'gowt1': {'AF_scale': 42.43, 'dsm': {'AF_alpha': 5e-4}, 'global-energy-minimization': {'AF_beta': 0.66}},
+        'explicit_override': {'AF_scale': 25, 'dsm': {'alpha': 0.7, 'AF_smooth_amount': 0.1}, 'preprocess': {'sigma2': 33}},
+    }
+    for key, base in tasks.items():
+        cfg, scale = superdsm.automation.create_config(pipeline, superdsm.config.Config(json.loads(json.dumps(base))), None)
+        out[key] = dict(base=base, scale=scale, expanded=cfg.entries)
+    with open(os.path.join(HERE, 'config.json'), 'w') as fp:
+        json.dump(out, fp, indent=1, sort_keys=True)
+    print('config.json')
+
+
+class _FakeObj:
+    def __init__(self, fp, energy, is_optimal=True):
+        self.footprint = set(fp)
+        self.energy = energy
+        self.is_optimal = is_optimal
+
+
+def gen_setcover(scene):
+    g, y, atoms, clusters, seeds = scene
+    adj = superdsm.atoms.AtomAdjacencyGraph(atoms, clusters, y > 0, seeds, out='muted')
+    rng = np.random.default_rng(21)
+    adj_dump = {
+        'atom_labels': sorted(int(a) for a in adj.atom_labels),
+        'cluster_labels': sorted(int(c) for c in adj.cluster_labels),
+        'adjacency': {str(a): sorted(int(b) for b in adj[a]) for a in adj.atom_labels},
+        'cluster_of_atom': {str(a): int(adj.get_cluster_label(a)) for a in adj.atom_labels},
+        'seeds': {str(a): [int(v) for v in adj.get_seed(a)] for a in adj.atom_labels},
+    }
+    # energy table for every connected subset up to size 4 (fake energies: sub-additive-ish with noise)
+    cands = synth.enumerate_candidates(adj, max_size=4)
+    atom_energy = {a: float(rng.uniform(40, 160)) for a in adj.atom_labels}
+    table = {}
+    for fp in cands:
+        base = sum(atom_energy[a] for a in fp)
+        table[','.join(map(str, fp))] = float(base * rng.uniform(0.55, 1.25)) if len(fp) > 1 else float(base)
+    energy_of = lambda fp: table[','.join(map(str, sorted(fp)))]
+
+    results = {}
+    for beta in (0.0, 60.0, 150.0):
+        for pruning in ('exact', 'isbi24'):
+            calls = []
+
+            def fake_compute_objects(objects, y_img, atoms_map, dsm_cfg, log_root_dir, status_line=None, out=None):
+                objects = list(objects)
+                calls.append([sorted(int(a) for a in o.footprint) for o in objects])
+                for o in objects:
+                    o.energy = energy_of(o.footprint)
+                    o.is_optimal = True
+                    o.on_boundary = False
+                    o.processing_time = 0
+                    o.fg_offset = np.zeros(2, int)
+                    o.fg_fragment = np.zeros((1, 1), bool)
+
+            rgem.compute_objects = fake_compute_objects
+            gens, costs, cover, objects, perf = rgem._compute_generations(
+                adj, None, atoms, None, pruning, {}, beta=beta, max_iter=5, gamma=0.8, out='muted')
+            results[f'beta{beta:g}_{pruning}'] = dict(
+                batches=calls, costs=[float(c) for c in costs],
+                solution=sorted(sorted(int(a) for a in o.footprint) for o in cover.solution),
+                n_objects=len(objects),
+                performance={k: int(getattr(perf, k)) for k in rgem.PerformanceReport.attributes},
+                generations=[[sorted(int(a) for a in o.footprint) for o in gen] for gen in gens])
+    # plain solve_minsetcover / maxsetpack on a random family
+    fam = [_FakeObj(fp, energy_of(fp)) for fp in cands if len(fp) <= 3]
+    msc = {}
+    for beta in (0.0, 80.0):
+        sol = rmsc.solve_minsetcover(fam, beta, out='muted')
+        msc[f'beta{beta:g}'] = sorted(sorted(int(a) for a in o.footprint) for o in sol)
+    pack_sol = superdsm.maxsetpack.solve_maxsetpack(fam, out='muted')
+    with open(os.path.join(HERE, 'setcover.json'), 'w') as fp:
+        json.dump(dict(adjacency=adj_dump, energy_table=table, generations=results, minsetcover=msc,
+                       maxsetpack=sorted(sorted(int(a) for a in o.footprint) for o in pack_sol)), fp)
+    save('setcover_scene', atoms=atoms.astype(np.int32), clusters=clusters.astype(np.int32),
+         fg=np.packbits((y > 0).reshape(-1)), seeds=np.asarray(seeds), shape=np.asarray(y.shape))
+    print('setcover.json')
+
+
+def main():
+    what = set(sys.argv[1:]) or {'preprocess', 'region', 'smoothmat', 'energy', 'optimum', 'config', 'setcover'}
+    scene = make_scene((128, 160), 7, 13, 31, sigma2=10)
+    if 'preprocess' in what: gen_preprocess()
+    if 'region' in what: gen_region(scene)
+    if 'smoothmat' in what: gen_smoothmat()
+    if 'energy' in what: gen_energy(scene)
+    if 'optimum' in what:
+        gen_optimum(scene, 'bbbc039_params', DSM_CFG)
+        scene2 = make_scene((200, 220), 4, 34, 32, sigma2=20)
+        gen_optimum(scene2, 'large_sigma', dict(DSM_CFG, smooth_amount=8, smooth_subsample=16, background_margin=16, alpha=0.9))
+    if 'config' in what: gen_config()
+    if 'setcover' in what:
+        scene3 = make_scene((160, 200), 14, 12, 33, sigma2=10)
+        gen_setcover(scene3)
+
+
+if __name__ == '__main__':
+    main()
