@@ -1,0 +1,157 @@
+/*
+ * sdsm.h -- C ABI of the MI355X-native SuperDSM hot path (libsdsm_hip.so).
+ *
+ * The reference (BMCV/SuperDSM @ 2024_08_07) has no FFI for this path: its only native boundary is MKL via
+ * ctypes (superdsm/_mkl.py:1-8, superdsm/_libs/sparse_dot_mkl/_mkl_interface.py:6-135) and cvxopt's C
+ * extension behind `cvxopt.solvers.cp` (superdsm/dsm.py:488).  This header is the boundary a maintainer
+ * would bind instead (see INTEGRATION.md for the ctypes stub): it replaces, per entry point,
+ *
+ *   sdsm_preprocess            Preprocessing.process                superdsm/preprocess.py:39-68
+ *   sdsm_image_prepare         the candidate-independent half of    superdsm/objects.py:95-128
+ *                              Object.get_cvxprog_region (EDT(y<=0) <= margin, per-atom extents)
+ *   sdsm_plan_* / sdsm_batch_* compute_objects / _compute_object    superdsm/objects.py:177-284
+ *                              cvxprog + Energy + CP.solve          superdsm/objects.py:361-412, dsm.py:253-490
+ *                              SmoothMatrixFactory.get              superdsm/dsm.py:137-237
+ *   sdsm_dsm_config            DSM_CONFIG_DEFAULTS                  superdsm/dsmcfg.py:6-21
+ *
+ * Conventions: extern "C", plain pointers and sizes, no C++ / torch types.  Every function returns 0 on
+ * success and a negative sdsm_status on failure; sdsm_last_error() returns a thread-local message.
+ * All device buffers are allocated and freed by the caller (PyTorch-ROCm tensors on the Python side) and
+ * passed as raw device pointers; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Calls on one stream are ordered; nothing here synchronises the device except where stated.
+ * There is no CPU backend: without a HIP device every compute entry point fails with SDSM_ERR_DEVICE.
+ */
+#ifndef SDSM_H
+#define SDSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDSM_VERSION 100
+
+typedef enum {
+    SDSM_OK = 0,
+    SDSM_ERR_ARGUMENT = -1,
+    SDSM_ERR_DEVICE = -2,      /* HIP runtime error / no device */
+    SDSM_ERR_WORKSPACE = -3,   /* caller-provided buffer too small */
+    SDSM_ERR_UNSUPPORTED = -4
+} sdsm_status;
+
+/* Hyper-parameters of the operator: DSM_CONFIG_DEFAULTS (dsmcfg.py:6-21) minus the keys that are
+ * meaningless on the GPU (cachesize, cachetest, smooth_mat_max_allocations, smooth_mat_dtype = float32
+ * construction is always used, cp_timeout is replaced by the iteration cap). */
+typedef struct {
+    double scale;                      /* dsm/scale (1000) */
+    double epsilon;                    /* dsm/epsilon (1.0) */
+    double alpha;                      /* dsm/alpha */
+    double smooth_amount;              /* dsm/smooth_amount, sigma_G; +inf = elliptical models only (c2freganal.py:126) */
+    double gaussian_shape_multiplier;  /* dsm/gaussian_shape_multiplier (2) */
+    double background_margin;          /* dsm/background_margin */
+    int32_t smooth_subsample;          /* dsm/smooth_subsample */
+    int32_t init_elliptical;           /* dsm/init == 'elliptical' */
+    int32_t max_iters;                 /* Newton iteration cap per solve (100 = cvxopt's maxiters) */
+    int32_t reserved;
+} sdsm_dsm_config;
+
+/* One candidate's result (objects.py:198-211).  128 bytes, written by the device. */
+typedef struct {
+    double energy;          /* psi(result), unscaled (objects.py:208) */
+    double theta[6];        /* a1,a2,a3,b1,b2,c in full-image-normalised coordinates (dsm.py:49-54) */
+    double energy_ell;      /* psi of the elliptical solution the DSM solve started from */
+    int32_t status;         /* sdsm_cand_status */
+    int32_t flags;          /* bit0: elliptical retry from the moment initialisation (objects.py:337-355) */
+    int32_t n_pixels;       /* N = region pixels */
+    int32_t n_deform;       /* M = deformation parameters (grid points) */
+    int32_t iters_ell, iters_dsm;   /* Newton iterations */
+    int32_t evals_value;    /* pixel passes that computed psi only */
+    int32_t evals_full;     /* pixel passes that computed psi, gradient and Hessian */
+    int32_t on_boundary;    /* S > 0 anywhere on the 1-px pad ring (objects.py:209) */
+    int32_t fg_r0, fg_c0, fg_h, fg_w;   /* bounding box of the foreground fragment; fg_h == 0: empty */
+    int32_t reserved[3];
+} sdsm_record;
+
+typedef enum {
+    SDSM_CAND_OPTIMAL = 0,      /* is_optimal = True */
+    SDSM_CAND_FALLBACK = 1,     /* DSM solve failed, elliptical result returned (objects.py:406-410) */
+    SDSM_CAND_TRIVIAL = 2,      /* single positive pixel (objects.py:184-191): energy 0, is_optimal False */
+    SDSM_CAND_ERROR = 3,        /* CvxprogError (objects.py:351-353) or malformed G~ (dsm.py:194) */
+    SDSM_CAND_UNSUPPORTED = 4   /* exceeds an implementation limit; elliptical result returned */
+} sdsm_cand_status;
+
+/* Per-atom statistics written by sdsm_image_prepare: for label l (1..n_atoms) six int32 at [6*l]:
+ * area (pixels with atoms == l, y_mask and EDT(y<=0) <= margin), rmin, rmax, cmin, cmax, reserved. */
+#define SDSM_ATOM_STATS_STRIDE 6
+
+/* ---- library --------------------------------------------------------------------------------- */
+int sdsm_version(void);
+const char *sdsm_last_error(void);
+int sdsm_device_count(void);
+int sdsm_set_device(int device);
+/* Blocks until all work queued on `stream` has finished. */
+int sdsm_stream_synchronize(void *stream);
+
+/* Gaussian PSF of G~ (dsm.py:137-142, float32 cast dsm.py:226).  Host function.  Returns k (the PSF is
+ * k x k); writes k*k floats if `out` != NULL. */
+int sdsm_psf(double sigma, double multiplier, float *out);
+
+/* ---- preprocessing (preprocess.py:39-68) ------------------------------------------------------- */
+size_t sdsm_preprocess_workspace_bytes(int H, int W, double sigma1, double sigma2);
+/* d_g: H*W float64 in [0,1] (pipeline.py:192), d_y: H*W float64 out.  Device pointers. */
+int sdsm_preprocess(const double *d_g, int H, int W, double sigma1, double sigma2, double offset_clip,
+                    int lower_clip_mean, double *d_y, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- per-image preparation --------------------------------------------------------------------- */
+size_t sdsm_image_workspace_bytes(int H, int W);
+/* d_y float64 H*W, d_y_mask uint8 H*W (NULL = all True), d_atoms int32 H*W (labels 1..n_atoms, 0 = none).
+ * Outputs: d_valid uint8 H*W = y_mask & (EDT(y <= 0) <= margin)   (objects.py:126-127; image.py:82)
+ *          d_atom_stats int32 (n_atoms+1)*SDSM_ATOM_STATS_STRIDE. */
+int sdsm_image_prepare(const double *d_y, const uint8_t *d_y_mask, const int32_t *d_atoms, int H, int W,
+                       double background_margin, int n_atoms, uint8_t *d_valid, int32_t *d_atom_stats,
+                       void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- batch of candidates (one compute_objects call) ------------------------------------------- */
+typedef struct sdsm_plan sdsm_plan;   /* host-side plan: offsets into the workspace, launch order */
+
+/* atom_stats: HOST copy of d_atom_stats.  offsets[n+1]/labels[]: footprints in CSR form (objects.py:53). */
+sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t *atom_stats, const sdsm_dsm_config *cfg,
+                            int n, const int32_t *offsets, const int32_t *labels);
+void sdsm_plan_destroy(sdsm_plan *plan);
+size_t sdsm_plan_workspace_bytes(const sdsm_plan *plan);
+size_t sdsm_plan_mask_bytes(const sdsm_plan *plan);       /* total size of the bit-packed region-bbox masks */
+/* Per candidate i: mask_info[4*i..] = r0, c0, h, w of the region bounding box its mask bits cover (row-major,
+ * LSB-first within uint32 words), mask_offset[i] = byte offset into the mask buffer; n_pixels[i] = N. */
+int sdsm_plan_describe(const sdsm_plan *plan, int32_t *mask_info, int64_t *mask_offset, int32_t *n_pixels);
+/* Algorithmic bytes of the setup phase (crop reads + writes), for the roofline bookkeeping. */
+int64_t sdsm_plan_total_pixels(const sdsm_plan *plan);
+
+/* Copies the plan tables into the workspace (H2D, asynchronous on `stream`). */
+int sdsm_batch_upload(const sdsm_plan *plan, void *d_workspace, size_t workspace_bytes, void *stream);
+/* Region crops, G~ rows, elliptical + DSM solves, masks, records.  Everything stays on the device:
+ * d_records: n * sizeof(sdsm_record); d_masks: sdsm_plan_mask_bytes(); d_xi (optional, may be NULL):
+ * float64, sdsm_plan_xi_count() entries, candidate i's xi at xi_offset[i] (debug / tests). */
+int sdsm_batch_launch(const sdsm_plan *plan, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid,
+                      void *d_workspace, size_t workspace_bytes, sdsm_record *d_records, uint32_t *d_masks,
+                      double *d_xi, void *stream);
+int64_t sdsm_plan_xi_count(const sdsm_plan *plan);
+/* Workspace layout for inspection (parity tests of the crops / grid / G~ rows).  out[16], byte offsets into the
+ * workspace: 0 cand table, 1 cand state (M, status, ...: 64 B each), 2 crop_y f64, 3 crop_rc u32, 4 crop_cc u32,
+ * 5 ell_nnz u16, 6 grid u32, 7 ell_idx u16, 8 ell_w f32; then 9 zcap, 10 k, 11 sizeof(cand entry),
+ * 12 total_pixels, 13 total_ell entries; 14-15 reserved.  Candidate i's blocks start at crop offset
+ * sum(n_pixels[:i]), ELL offset that * zcap (slot-major inside the candidate) and grid offset xi_offset[i]. */
+int sdsm_plan_layout(const sdsm_plan *plan, int64_t *out);
+int sdsm_plan_xi_offsets(const sdsm_plan *plan, int64_t *xi_offset);
+
+/* Timing of the dominant kernel with HIP events on the launch stream: after sdsm_batch_launch returns,
+ * sdsm_last_solve_kernel_ms() synchronises on the recorded events and returns the solve kernels' duration. */
+int sdsm_enable_kernel_timing(int enable);
+double sdsm_last_solve_kernel_ms(void);
+double sdsm_last_setup_kernel_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDSM_H */

@@ -1,0 +1,302 @@
+// Host side of the C ABI (include/sdsm.h): planning, workspace layout, launches.  No device allocation
+// happens here: every device buffer is provided by the caller.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "sdsm_common.h"
+
+extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream);
+extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
+extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
+extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
+extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+static int hipfail(hipError_t e, const char *what) { return fail(SDSM_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
+
+extern "C" int sdsm_version(void) { return SDSM_VERSION; }
+extern "C" const char *sdsm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sdsm_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { hipfail(e, "hipGetDeviceCount"); return 0; }
+    return n;
+}
+
+extern "C" int sdsm_set_device(int device)
+{
+    hipError_t e = hipSetDevice(device);
+    return e == hipSuccess ? SDSM_OK : hipfail(e, "hipSetDevice");
+}
+
+extern "C" int sdsm_stream_synchronize(void *stream)
+{
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? SDSM_OK : hipfail(e, "hipStreamSynchronize");
+}
+
+// ---- PSF of G~ (dsm.py:137-142): delta image filtered with SciPy's gaussian_filter, float32 ----------
+static inline long reflect_h(long i, long n) { long p = 2 * n, m = i % p; if (m < 0) m += p; return m < n ? m : p - 1 - m; }
+
+static void correlate_line(const double *in, long n, long stride, const double *w, int R, double *out)
+{
+    std::vector<double> buf(n + 2 * R);
+    for (long i = -R; i < n + R; i++) buf[i + R] = in[reflect_h(i, n) * stride];
+    for (long l = 0; l < n; l++) {
+        const double *c = buf.data() + l + R;
+        double acc = c[0] * w[R];
+        for (int j = R; j >= 1; j--) acc += (c[-j] + c[j]) * w[R - j];
+        out[l * stride] = acc;
+    }
+}
+
+static int make_psf(double sigma, double mult, std::vector<float> &psf)
+{
+    int k = (int)std::nearbyint(1 + sigma * 4 * mult);
+    if (k < 1) k = 1;
+    int R = (int)(4.0 * sigma + 0.5);
+    std::vector<double> w(2 * R + 1), a((size_t)k * k, 0.0), b((size_t)k * k), c((size_t)k * k);
+    sdsm_gauss_kernel_host(sigma, R, w.data());
+    a[(size_t)(k / 2) * k + k / 2] = 1;
+    for (int col = 0; col < k; col++) correlate_line(a.data() + col, k, k, w.data(), R, b.data() + col);
+    for (int row = 0; row < k; row++) correlate_line(b.data() + (size_t)row * k, k, 1, w.data(), R, c.data() + (size_t)row * k);
+    psf.resize((size_t)k * k);
+    for (size_t i = 0; i < psf.size(); i++) psf[i] = (float)c[i];
+    return k;
+}
+
+extern "C" int sdsm_psf(double sigma, double multiplier, float *out)
+{
+    if (!(sigma > 0) || std::isinf(sigma)) return fail(SDSM_ERR_ARGUMENT, "sdsm_psf: sigma must be finite and positive");
+    std::vector<float> psf;
+    int k = make_psf(sigma, multiplier, psf);
+    if (out) memcpy(out, psf.data(), psf.size() * sizeof(float));
+    return k;
+}
+
+// ---- preprocessing / image prepare --------------------------------------------------------------------
+extern "C" size_t sdsm_preprocess_workspace_bytes(int H, int W, double sigma1, double sigma2);
+extern "C" size_t sdsm_image_workspace_bytes(int H, int W);
+
+extern "C" int sdsm_preprocess(const double *d_g, int H, int W, double sigma1, double sigma2, double offset_clip, int lower_clip_mean,
+                               double *d_y, void *d_ws, size_t ws_bytes, void *stream)
+{
+    if (!d_g || !d_y || H < 1 || W < 1 || !(sigma1 > 0) || !(sigma2 > 0)) return fail(SDSM_ERR_ARGUMENT, "sdsm_preprocess: bad argument");
+    if (ws_bytes < sdsm_preprocess_workspace_bytes(H, W, sigma1, sigma2) || !d_ws) return fail(SDSM_ERR_WORKSPACE, "sdsm_preprocess: workspace too small");
+    hipError_t e = sdsm_preprocess_impl(d_g, H, W, sigma1, sigma2, offset_clip, lower_clip_mean, d_y, d_ws, (hipStream_t)stream);
+    return e == hipSuccess ? SDSM_OK : hipfail(e, "sdsm_preprocess");
+}
+
+extern "C" int sdsm_image_prepare(const double *d_y, const uint8_t *d_y_mask, const int32_t *d_atoms, int H, int W, double margin,
+                                  int n_atoms, uint8_t *d_valid, int32_t *d_atom_stats, void *d_ws, size_t ws_bytes, void *stream)
+{
+    if (!d_y || !d_atoms || !d_valid || !d_atom_stats || H < 2 || W < 2 || H > 65535 || W > 65535 || n_atoms < 0)
+        return fail(SDSM_ERR_ARGUMENT, "sdsm_image_prepare: bad argument (image must be 2..65535 pixels per side)");
+    if (n_atoms > SDSM_MAX_LABELS) return fail(SDSM_ERR_UNSUPPORTED, "sdsm_image_prepare: more than 65535 atom labels");
+    if (!(margin >= 0)) return fail(SDSM_ERR_ARGUMENT, "sdsm_image_prepare: background_margin must be >= 0");
+    if (ws_bytes < sdsm_image_workspace_bytes(H, W) || !d_ws) return fail(SDSM_ERR_WORKSPACE, "sdsm_image_prepare: workspace too small");
+    hipError_t e = sdsm_image_prepare_impl(d_y, d_y_mask, d_atoms, H, W, margin, n_atoms, d_valid, d_atom_stats, d_ws, (hipStream_t)stream);
+    return e == hipSuccess ? SDSM_OK : hipfail(e, "sdsm_image_prepare");
+}
+
+// ---- plan ------------------------------------------------------------------------------------------------
+struct sdsm_plan {
+    int n = 0, H = 0, W = 0, n_atoms = 0;
+    sdsm_dsm_config cfg{};
+    int k = 1, R = 0, zcap = 1, no_deform = 0;
+    std::vector<CandDesc> cand;
+    std::vector<int32_t> fp_labels, order;
+    std::vector<float> psf;
+    std::vector<int32_t> mask_info, n_pixels;
+    std::vector<int64_t> mask_off_bytes, xi_off;
+    int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hsave = 0;
+    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0,
+           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_ell_nnz = 0, off_psf = 0, off_hsave = 0, total = 0;
+};
+
+static size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t *atom_stats, const sdsm_dsm_config *cfg,
+                                       int n, const int32_t *offsets, const int32_t *labels)
+{
+    if (!atom_stats || !cfg || n < 0 || (n > 0 && (!offsets || !labels)) || H < 2 || W < 2) { fail(SDSM_ERR_ARGUMENT, "sdsm_plan_create: bad argument"); return nullptr; }
+    if (!(cfg->epsilon > 0) || !(cfg->alpha >= 0) || !(cfg->scale > 0) || cfg->smooth_subsample < 1 || !(cfg->smooth_amount > 0)) {
+        fail(SDSM_ERR_ARGUMENT, "sdsm_plan_create: epsilon > 0, alpha >= 0, scale > 0, smooth_subsample >= 1, smooth_amount > 0 required (dsm.py:275-285)");
+        return nullptr;
+    }
+    sdsm_plan *p = new sdsm_plan();
+    p->n = n; p->H = H; p->W = W; p->n_atoms = n_atoms; p->cfg = *cfg;
+    if (p->cfg.max_iters <= 0) p->cfg.max_iters = 100;
+    p->no_deform = std::isinf(cfg->smooth_amount) ? 1 : 0;
+    if (!p->no_deform) {
+        p->k = make_psf(cfg->smooth_amount, cfg->gaussian_shape_multiplier, p->psf);
+        if (p->k % 2 == 0) {   // _convmat asserts an odd filter size (dsm.py:147)
+            fail(SDSM_ERR_ARGUMENT, "sdsm_plan_create: round(1 + 4 * smooth_amount * gaussian_shape_multiplier) must be odd (dsm.py:147)");
+            delete p; return nullptr;
+        }
+        p->R = p->k / 2;
+        long per = (2 * p->R) / cfg->smooth_subsample + 1;
+        long z = per * per;
+        p->zcap = (int)std::min<long>(z, 65535);
+    } else { p->psf.assign(1, 1.f); p->k = 1; p->R = 0; p->zcap = 1; }
+    const int s = cfg->smooth_subsample;
+    p->cand.resize(n); p->mask_info.resize((size_t)4 * n); p->mask_off_bytes.resize(n); p->xi_off.resize(n); p->n_pixels.resize(n);
+    p->fp_labels.assign(labels, labels + (n > 0 ? offsets[n] : 0));
+    for (int i = 0; i < n; i++) {
+        CandDesc &c = p->cand[i];
+        long N = 0; int r0 = H, r1 = -1, c0 = W, c1 = -1;
+        for (int e = offsets[i]; e < offsets[i + 1]; e++) {
+            int l = labels[e];
+            if (l < 1 || l > n_atoms) continue;
+            const int32_t *st = atom_stats + (size_t)l * SDSM_ATOM_STATS_STRIDE;
+            if (st[0] <= 0) continue;
+            N += st[0];
+            r0 = std::min(r0, st[1]); r1 = std::max(r1, st[2]); c0 = std::min(c0, st[3]); c1 = std::max(c1, st[4]);
+        }
+        if (r1 < 0) { r0 = c0 = 0; r1 = c1 = 0; N = 0; }
+        c.N = (int32_t)N; c.r0 = r0; c.c0 = c0; c.h = r1 - r0 + 1; c.w = c1 - c0 + 1;
+        c.fp_off = offsets[i]; c.fp_len = offsets[i + 1] - offsets[i];
+        long mc = p->no_deform ? 1 : (long)((c.h + s - 1) / s) * ((c.w + s - 1) / s);
+        c.Mcap = (int32_t)std::max<long>(1, std::min<long>(mc, std::max<long>(N, 1)));
+        c.crop_off = p->total_pixels; p->total_pixels += N;
+        c.ell_off = p->total_ell; p->total_ell += (int64_t)N * p->zcap;
+        c.xi_off = p->total_xi; p->total_xi += c.Mcap;
+        c.mask_off = p->total_mask_words; p->total_mask_words += ((int64_t)c.h * c.w + 31) / 32;
+        c.hsave_slot = (6 + c.Mcap > 84) ? (int32_t)p->n_hsave++ : -1;
+        c.pad = 0;
+        p->mask_info[4 * i] = r0; p->mask_info[4 * i + 1] = c0; p->mask_info[4 * i + 2] = c.h; p->mask_info[4 * i + 3] = c.w;
+        p->mask_off_bytes[i] = c.mask_off * 4; p->xi_off[i] = c.xi_off; p->n_pixels[i] = c.N;
+    }
+    p->order.resize(n);
+    std::iota(p->order.begin(), p->order.end(), 0);
+    std::stable_sort(p->order.begin(), p->order.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
+    // workspace layout
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+    p->off_cand = take(sizeof(CandDesc) * std::max(n, 1));
+    p->off_state = take(sizeof(CandState) * std::max(n, 1));
+    p->off_fp = take(4 * std::max<size_t>(p->fp_labels.size(), 1));
+    p->off_order = take(4 * (size_t)std::max(n, 1));
+    p->off_psf = take(4 * p->psf.size());
+    size_t np = (size_t)std::max<int64_t>(p->total_pixels, 1);
+    p->off_crop_y = take(8 * np);
+    p->off_crop_rc = take(4 * np);
+    p->off_crop_cc = take(4 * np);
+    p->off_dist = take(4 * np);
+    p->off_ell_nnz = take(2 * np);
+    p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
+    p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
+    p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
+    p->off_hsave = take(8 * (size_t)std::max<int64_t>(p->n_hsave, 1) * (SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2));
+    p->total = o;
+    return p;
+}
+
+extern "C" void sdsm_plan_destroy(sdsm_plan *plan) { delete plan; }
+extern "C" size_t sdsm_plan_workspace_bytes(const sdsm_plan *p) { return p ? p->total : 0; }
+extern "C" size_t sdsm_plan_mask_bytes(const sdsm_plan *p) { return p ? (size_t)std::max<int64_t>(p->total_mask_words, 1) * 4 : 0; }
+extern "C" int64_t sdsm_plan_total_pixels(const sdsm_plan *p) { return p ? p->total_pixels : 0; }
+extern "C" int64_t sdsm_plan_xi_count(const sdsm_plan *p) { return p ? std::max<int64_t>(p->total_xi, 1) : 0; }
+
+extern "C" int sdsm_plan_describe(const sdsm_plan *p, int32_t *mask_info, int64_t *mask_offset, int32_t *n_pixels)
+{
+    if (!p) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_describe: null plan");
+    if (mask_info) memcpy(mask_info, p->mask_info.data(), p->mask_info.size() * 4);
+    if (mask_offset) memcpy(mask_offset, p->mask_off_bytes.data(), p->mask_off_bytes.size() * 8);
+    if (n_pixels) memcpy(n_pixels, p->n_pixels.data(), p->n_pixels.size() * 4);
+    return SDSM_OK;
+}
+
+extern "C" int sdsm_plan_xi_offsets(const sdsm_plan *p, int64_t *xi_offset)
+{
+    if (!p || !xi_offset) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_xi_offsets: null argument");
+    memcpy(xi_offset, p->xi_off.data(), p->xi_off.size() * 8);
+    return SDSM_OK;
+}
+
+extern "C" int sdsm_plan_layout(const sdsm_plan *p, int64_t *out)
+{
+    if (!p || !out) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_layout: null argument");
+    int64_t v[16] = {(int64_t)p->off_cand, (int64_t)p->off_state, (int64_t)p->off_crop_y, (int64_t)p->off_crop_rc, (int64_t)p->off_crop_cc,
+                     (int64_t)p->off_ell_nnz, (int64_t)p->off_grid, (int64_t)p->off_ell_idx, (int64_t)p->off_ell_w, p->zcap, p->k,
+                     (int64_t)sizeof(CandDesc), p->total_pixels, p->total_ell, 0, 0};
+    memcpy(out, v, sizeof(v));
+    return SDSM_OK;
+}
+
+extern "C" int sdsm_batch_upload(const sdsm_plan *p, void *d_ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !d_ws) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_upload: null argument");
+    if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_upload: workspace too small");
+    if (p->n == 0) return SDSM_OK;
+    uint8_t *b = (uint8_t *)d_ws;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if ((e = hipMemcpyAsync(b + p->off_cand, p->cand.data(), sizeof(CandDesc) * p->n, hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload cand");
+    if (!p->fp_labels.empty() && (e = hipMemcpyAsync(b + p->off_fp, p->fp_labels.data(), 4 * p->fp_labels.size(), hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload footprints");
+    if ((e = hipMemcpyAsync(b + p->off_order, p->order.data(), 4 * (size_t)p->n, hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload order");
+    if ((e = hipMemcpyAsync(b + p->off_psf, p->psf.data(), 4 * p->psf.size(), hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload psf");
+    return SDSM_OK;
+}
+
+static thread_local int g_timing = 0;
+static thread_local hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+static thread_local int g_ev_valid = 0;
+
+extern "C" int sdsm_enable_kernel_timing(int enable)
+{
+    g_timing = enable;
+    if (enable && !g_ev[0]) {
+        for (int i = 0; i < 3; i++) { hipError_t e = hipEventCreate(&g_ev[i]); if (e != hipSuccess) return hipfail(e, "hipEventCreate"); }
+    }
+    return SDSM_OK;
+}
+
+static double elapsed(int a, int b)
+{
+    if (!g_ev_valid) return -1.0;
+    if (hipEventSynchronize(g_ev[b]) != hipSuccess) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g_ev[a], g_ev[b]) != hipSuccess) return -1.0;
+    return ms;
+}
+extern "C" double sdsm_last_setup_kernel_ms(void) { return elapsed(0, 1); }
+extern "C" double sdsm_last_solve_kernel_ms(void) { return elapsed(1, 2); }
+
+extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid,
+                                 void *d_ws, size_t ws_bytes, sdsm_record *d_records, uint32_t *d_masks, double *d_xi, void *stream)
+{
+    if (!p || !d_y || !d_atoms || !d_valid || !d_ws || !d_records || !d_masks) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: null argument");
+    if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_launch: workspace too small");
+    if (p->n == 0) return SDSM_OK;
+    uint8_t *b = (uint8_t *)d_ws;
+    hipStream_t s = (hipStream_t)stream;
+    BatchParams P{};
+    P.n = p->n; P.H = p->H; P.W = p->W; P.n_atoms = p->n_atoms;
+    P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.no_deform = p->no_deform;
+    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters;
+    P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
+    P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);
+    P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);
+    P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);
+    P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
+    P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_nnz = (uint16_t *)(b + p->off_ell_nnz);
+    P.psf = (const float *)(b + p->off_psf);
+    P.hsave = (double *)(b + p->off_hsave); P.hsave_stride = SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2;
+    hipError_t e;
+    if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
+    if ((e = sdsm_launch_setup(P, d_y, d_atoms, d_valid, s)) != hipSuccess) return hipfail(e, "launch setup");
+    if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s)) != hipSuccess) return hipfail(e, "launch solve");
+    if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
+    return SDSM_OK;
+}

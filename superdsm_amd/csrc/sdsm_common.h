@@ -1,0 +1,134 @@
+// Shared device-side structures and workgroup primitives (gfx950, wave64, 256-thread workgroups).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sdsm.h"
+
+#define SDSM_WG 256
+#define SDSM_WAVES (SDSM_WG / 64)
+
+// limits of this implementation (DESIGN.md "Limits")
+#define SDSM_MAX_LABELS 65535      // footprint bitset in LDS
+#define SDSM_MAX_BBOX_DIM 4096     // row / column rank tables in LDS
+#define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
+#define SDSM_MAX_N_SOLVE 172       // 6 + M handled by the largest solve class
+
+enum { ST_OK = 0, ST_TRIVIAL = 2, ST_ERROR = 3, ST_UNSUPPORTED = 4 };
+
+// Host-planned description of one candidate (read-only on the device).
+struct CandDesc {
+    int64_t crop_off;   // first pixel of the candidate's packed crop (crop_y / crop_rc / crop_cc / ell_nnz)
+    int64_t ell_off;    // first entry of its ELL block (N * zcap entries, slot-major)
+    int64_t mask_off;   // first uint32 word of its bit-packed region-bbox mask
+    int64_t xi_off;     // first entry of its grid / xi block (Mcap entries)
+    int32_t N;          // region pixels (sum of the atoms' valid areas)
+    int32_t r0, c0, h, w;   // region bounding box (union of the atoms' valid extents)
+    int32_t fp_off, fp_len; // footprint labels
+    int32_t Mcap;       // upper bound of M
+    int32_t hsave_slot; // slot in the global Hessian-copy pool (only candidates that may reach the in-place class), else -1
+    int32_t pad;
+};
+
+// Written by the setup kernel.
+struct CandState {
+    int32_t M;          // number of grid points (columns of G~)
+    int32_t status;     // ST_*
+    int32_t hc, wc;     // shape of the mask after deleting empty rows / columns (dsm.py:185-186)
+    int32_t npos;       // region pixels with y > 0
+    int32_t pad;
+    unsigned long long sum_r, sum_c, sum_rr, sum_cc;   // moments of the y > 0 pixels (image coordinates)
+    unsigned long long reserved;
+};
+static_assert(sizeof(CandState) == 64, "CandState layout");
+static_assert(sizeof(CandDesc) == 72, "CandDesc layout");
+
+struct BatchParams {
+    int32_t n, H, W, n_atoms;
+    int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, ELL slots per pixel
+    int32_t no_deform;                 // smooth_amount == inf
+    int32_t init_elliptical, max_iters, pad0;
+    double scale, epsilon, alpha;
+    const CandDesc *cand;
+    CandState *state;
+    const int32_t *fp_labels;
+    const int32_t *order;              // workgroup -> candidate (largest first)
+    double *crop_y;                    // 8 B / pixel
+    uint32_t *crop_rc;                 // (row << 16) | col, image coordinates: 4 B / pixel
+    uint32_t *crop_cc;                 // compressed coordinates (setup only)
+    uint32_t *dist;                    // chessboard distance to the nearest grid point (setup only)
+    uint32_t *grid_rc;                 // sorted grid points, compressed coordinates
+    uint16_t *ell_idx;
+    float *ell_w;
+    uint16_t *ell_nnz;
+    const float *psf;
+    double *hsave;                     // per-candidate Hessian copy for the in-place class
+    int64_t hsave_stride;
+};
+
+// ---------------------------------------------------------------------------------------------
+// workgroup primitives
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum over the workgroup, result broadcast to every thread.  `scratch` holds >= SDSM_WAVES doubles.
+__device__ __forceinline__ double block_sum(double v, double *scratch)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0;
+#pragma unroll
+    for (int i = 0; i < SDSM_WAVES; i++) r += scratch[i];
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, unsigned long long *scratch)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < SDSM_WAVES; i++) r = scratch[i] < r ? scratch[i] : r;
+    return r;
+}
+
+__device__ __forceinline__ int block_min_i32(int v, int *scratch)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < SDSM_WAVES; i++) r = scratch[i] < r ? scratch[i] : r;
+    return r;
+}
+
+// Exclusive prefix count of `flag` over the workgroup in thread order; *total = number of set flags.
+__device__ __forceinline__ int block_excl_count(bool flag, int *scratch /* SDSM_WAVES ints */, int *total)
+{
+    unsigned long long m = __ballot(flag);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int within = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) scratch[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SDSM_WAVES; i++) { if (i < wave) before += scratch[i]; tot += scratch[i]; }
+    *total = tot;
+    return before + within;
+}

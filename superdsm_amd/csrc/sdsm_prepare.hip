@@ -1,0 +1,328 @@
+// Per-image kernels: bounded exact Euclidean distance tests, per-atom statistics, and the Gaussian
+// scale-space preprocessing (separable stencils staged through LDS).
+//
+// Reference behaviour restated here (never its code):
+//   Preprocessing.process                 superdsm/preprocess.py:39-68  (SciPy gaussian_filter: mode='reflect',
+//                                         truncate=4; symmetric correlate1d association order)
+//   EDT(y <= 0) <= background_margin      superdsm/objects.py:126-127   (candidate independent)
+#include "sdsm_common.h"
+
+#pragma clang fp contract(off)   // keep SciPy's / numpy's unfused association (bit-level parity of y)
+
+extern __shared__ __align__(16) unsigned char sdsm_dyn_lds[];
+
+namespace {
+
+// ---- target masks --------------------------------------------------------------------------------
+// mode 0: target = y > 0                (EDT(y <= 0): distance to the nearest pixel with y > 0)
+// mode 1: target = g > scal[2]          (clip_area, preprocess.py:55)
+__global__ void k_target(const double *__restrict__ src, size_t n, int mode, const double *__restrict__ scal,
+                         uint8_t *__restrict__ target, int *__restrict__ any)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool t = false;
+    if (i < n) {
+        double thr = mode == 0 ? 0.0 : scal[2];
+        t = src[i] > thr;
+        target[i] = t;
+    }
+    if (__any(t) && (threadIdx.x & 63) == 0) atomicOr(any, 1);
+}
+
+// horizontal distance to the nearest target in the same row, capped at radius + 1
+__global__ void k_hdist(const uint8_t *__restrict__ target, int H, int W, int radius, uint16_t *__restrict__ hd)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const uint8_t *row = target + (size_t)r * W;
+    int d = radius + 1;
+    for (int k = 0; k <= radius; k++) {
+        if ((c - k >= 0 && row[c - k]) || (c + k < W && row[c + k])) { d = k; break; }
+    }
+    hd[(size_t)r * W + c] = (uint16_t)d;
+}
+
+// squared Euclidean distance to the nearest target if it is <= radius^2 (exact), else "far".
+// out_valid != NULL: valid = y_mask & (d2 <= m2)            (image prepare)
+// out_t     != NULL: t = max(sigma2 - sqrt(d2), 0)           (preprocess.py:56-57)
+__global__ void k_vdist(const uint16_t *__restrict__ hd, int H, int W, int radius, const int *__restrict__ any,
+                        double m2, const uint8_t *__restrict__ y_mask, uint8_t *__restrict__ out_valid,
+                        double sigma2, double *__restrict__ out_t)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    long long best = -1;
+    if (!*any) best = (long long)(r + 1) * (r + 1) + (long long)c * c;   // SciPy's behaviour without any background pixel
+    else {
+        int lo = r - radius < 0 ? 0 : r - radius, hi = r + radius >= H ? H - 1 : r + radius;
+        for (int rr = lo; rr <= hi; rr++) {
+            int h = hd[(size_t)rr * W + c];
+            if (h > radius) continue;
+            long long d2 = (long long)(rr - r) * (rr - r) + (long long)h * h;
+            if (best < 0 || d2 < best) best = d2;
+        }
+    }
+    size_t p = (size_t)r * W + c;
+    if (out_valid) out_valid[p] = (best >= 0 && (double)best <= m2) && (y_mask ? y_mask[p] != 0 : true);
+    if (out_t) {
+        double t = best < 0 ? 0.0 : sigma2 - sqrt((double)best);
+        out_t[p] = t < 0 ? 0.0 : t;
+    }
+}
+
+__global__ void k_stats_init(int32_t *stats, int n_atoms)
+{
+    int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > n_atoms) return;
+    int32_t *s = stats + (size_t)l * SDSM_ATOM_STATS_STRIDE;
+    s[0] = 0; s[1] = 0x7fffffff; s[2] = -1; s[3] = 0x7fffffff; s[4] = -1; s[5] = 0;
+}
+
+__global__ void k_stats(const int32_t *__restrict__ atoms, const uint8_t *__restrict__ valid, int H, int W, int n_atoms, int32_t *stats)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    size_t p = (size_t)r * W + c;
+    int l = atoms[p];
+    if (l < 1 || l > n_atoms || !valid[p]) return;
+    int32_t *s = stats + (size_t)l * SDSM_ATOM_STATS_STRIDE;
+    atomicAdd(&s[0], 1);
+    atomicMin(&s[1], r); atomicMax(&s[2], r);
+    atomicMin(&s[3], c); atomicMax(&s[4], c);
+}
+
+// ---- reductions for np.std (preprocess.py:52) ------------------------------------------------------
+// mode 0: sum(x), mode 1: sum((x - scal[0])^2).  Deterministic two-level tree (not numpy's pairwise order:
+// the mean / std may differ from numpy's in the last ulp).
+__global__ void k_partial(const double *__restrict__ x, size_t n, int mode, const double *__restrict__ scal, double *__restrict__ partial)
+{
+    __shared__ double red[SDSM_WAVES];
+    double mean = mode ? scal[0] : 0.0;
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = x[i];
+        if (mode) { v = v - mean; v = v * v; }
+        s += v;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void k_final(const double *__restrict__ partial, int np, double n, int mode, double offset_clip, double *__restrict__ scal)
+{
+    __shared__ double red[SDSM_WAVES];
+    double s = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        if (mode == 0) scal[0] = s / n;                                  // mean
+        else { scal[1] = sqrt(s / n); scal[2] = offset_clip * scal[1]; }  // std, clip_abs
+    }
+}
+
+__global__ void k_clip(const double *__restrict__ g, size_t n, const double *__restrict__ scal, double *__restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double hi = scal[2], v = g[i];
+    out[i] = v < 0 ? 0 : (v > hi ? hi : v);                               // g_raw.clip(0, clip_abs)
+}
+
+// ---- separable Gaussian, reflect boundary, SciPy's symmetric association order -----------------------
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    int p = 2 * n;
+    int m = i % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - 1 - m;
+}
+
+// axis 1: one workgroup = 256 consecutive pixels of one row (+ halo) staged in LDS
+__global__ __launch_bounds__(256) void k_gauss_rows(const double *__restrict__ in, int H, int W, const double *__restrict__ w, int R, double *__restrict__ out)
+{
+    double *lds = (double *)sdsm_dyn_lds;
+    const int r = blockIdx.y, c0 = blockIdx.x * 256, tid = threadIdx.x;
+    const double *row = in + (size_t)r * W;
+    for (int i = tid; i < 256 + 2 * R; i += 256) lds[i] = row[reflect_idx(c0 - R + i, W)];
+    __syncthreads();
+    int c = c0 + tid;
+    if (c >= W) return;
+    const double *ctr = lds + tid + R;
+    double acc = ctr[0] * w[R];
+    for (int j = R; j >= 1; j--) acc += (ctr[-j] + ctr[j]) * w[R - j];
+    out[(size_t)r * W + c] = acc;
+}
+
+// axis 0: one workgroup = 32 columns x 64 rows (+ halo rows) staged in LDS; thread = (column, 8 rows)
+#define GC_COLS 32
+#define GC_ROWS 64
+__global__ __launch_bounds__(256) void k_gauss_cols(const double *__restrict__ in, int H, int W, const double *__restrict__ w, int R, double *__restrict__ out)
+{
+    double *lds = (double *)sdsm_dyn_lds;
+    const int c0 = blockIdx.x * GC_COLS, r0 = blockIdx.y * GC_ROWS, tid = threadIdx.x;
+    const int lc = tid % GC_COLS, lr = tid / GC_COLS;          // 32 x 8
+    const int rows = GC_ROWS + 2 * R;
+    const int c = c0 + lc;
+    const int cs = c < W ? c : W - 1;
+    for (int i = lr; i < rows; i += 8) lds[i * GC_COLS + lc] = in[(size_t)reflect_idx(r0 - R + i, H) * W + cs];
+    __syncthreads();
+    if (c >= W) return;
+    for (int k = 0; k < GC_ROWS / 8; k++) {
+        int rl = lr + 8 * k, r = r0 + rl;
+        if (r >= H) break;
+        const double *ctr = lds + (rl + R) * GC_COLS + lc;
+        double acc = ctr[0] * w[R];
+        for (int j = R; j >= 1; j--) acc += (ctr[-j * GC_COLS] + ctr[j * GC_COLS]) * w[R - j];
+        out[(size_t)r * W + c] = acc;
+    }
+}
+
+// y = gauss(g, sigma1) - ((1 - t) * offset_clipped + t * offset_original),  t = (t / tmax)^2   (preprocess.py:57-64)
+__global__ void k_combine(const double *__restrict__ g1, const double *__restrict__ off, const double *__restrict__ offc,
+                          const double *__restrict__ tbuf, size_t n, int use_clip, int lower_clip_mean,
+                          const double *__restrict__ scal, const int *__restrict__ any, double sigma2, double *__restrict__ y)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double comb;
+    if (use_clip) {
+        // max of (sigma2 - d).clip(0): d == 0 on the clipped pixels; without any, SciPy's virtual pixel gives d_min = 1
+        double tmax = *any ? sigma2 : (sigma2 - 1.0 < 0 ? 0.0 : sigma2 - 1.0);
+        double t = tbuf[i] / tmax;
+        t = t * t;
+        comb = (1 - t) * offc[i] + t * off[i];
+    } else comb = off[i];
+    if (lower_clip_mean) { double mean = scal[0]; if (!(comb > mean)) comb = mean; }
+    y[i] = g1[i] - comb;
+}
+
+}  // namespace
+
+// ---- host side --------------------------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t sdsm_image_workspace_bytes(int H, int W)
+{
+    size_t n = (size_t)H * W;
+    return align_up(n, 256) /* target */ + align_up(n * 2, 256) /* hd */ + 256 /* flags */;
+}
+
+extern "C" hipError_t sdsm_image_prepare_impl(const double *d_y, const uint8_t *d_y_mask, const int32_t *d_atoms, int H, int W,
+                                              double margin, int n_atoms, uint8_t *d_valid, int32_t *d_atom_stats,
+                                              void *d_ws, hipStream_t stream)
+{
+    size_t n = (size_t)H * W;
+    uint8_t *target = (uint8_t *)d_ws;
+    uint16_t *hd = (uint16_t *)((uint8_t *)d_ws + align_up(n, 256));
+    int *any = (int *)((uint8_t *)hd + align_up(n * 2, 256));
+    hipError_t e = hipMemsetAsync(any, 0, 256, stream);
+    if (e != hipSuccess) return e;
+    int radius = (int)ceil(margin);
+    if (radius < 0) radius = 0;
+    dim3 b(256), g2((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_target, dim3((n + 255) / 256), b, 0, stream, d_y, n, 0, (const double *)nullptr, target, any);
+    hipLaunchKernelGGL(k_hdist, g2, b, 0, stream, target, H, W, radius, hd);
+    hipLaunchKernelGGL(k_vdist, g2, b, 0, stream, hd, H, W, radius, any, margin * margin, d_y_mask, d_valid, 0.0, (double *)nullptr);
+    hipLaunchKernelGGL(k_stats_init, dim3((n_atoms + 256) / 256), b, 0, stream, d_atom_stats, n_atoms);
+    hipLaunchKernelGGL(k_stats, g2, b, 0, stream, d_atoms, d_valid, H, W, n_atoms, d_atom_stats);
+    return hipGetLastError();
+}
+
+static int gauss_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
+
+extern "C" size_t sdsm_preprocess_workspace_bytes(int H, int W, double sigma1, double sigma2)
+{
+    size_t n = (size_t)H * W;
+    size_t r1 = gauss_radius(sigma1), r2 = gauss_radius(sigma2);
+    return 4 * align_up(n * 8, 256) + align_up(n, 256) + align_up(n * 2, 256) + align_up((2 * r1 + 1 + 2 * r2 + 1) * 8, 256)
+           + align_up(1024 * 8, 256) + 512;
+}
+
+// numpy pairwise sum (PW_BLOCKSIZE 128), host
+static double np_pairwise(const double *a, long n)
+{
+    if (n < 8) { double r = 0; for (long i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8]; long i;
+        for (int k = 0; k < 8; k++) r[k] = a[k];
+        for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    long n2 = n / 2; n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+
+// scipy.ndimage._filters._gaussian_kernel1d
+extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w)
+{
+    double s2 = sigma * sigma;
+    for (int i = 0; i <= 2 * radius; i++) { double x = i - radius; w[i] = exp(-0.5 / s2 * (x * x)); }
+    double s = np_pairwise(w, 2 * radius + 1);
+    for (int i = 0; i <= 2 * radius; i++) w[i] = w[i] / s;
+}
+
+static hipError_t gauss2d(const double *in, int H, int W, const double *d_w, int R, double *tmp, double *out, hipStream_t stream)
+{
+    size_t lds_c = (size_t)(GC_ROWS + 2 * R) * GC_COLS * 8, lds_r = (size_t)(256 + 2 * R) * 8;
+    if (lds_c > 160 * 1024 - 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)k_gauss_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gauss_cols, dim3((W + GC_COLS - 1) / GC_COLS, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w, R, tmp);
+    hipLaunchKernelGGL(k_gauss_rows, dim3((W + 255) / 256, H), dim3(256), lds_r, stream, (const double *)tmp, H, W, d_w, R, out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t sdsm_preprocess_impl(const double *d_g, int H, int W, double sigma1, double sigma2, double offset_clip,
+                                           int lower_clip_mean, double *d_y, void *d_ws, hipStream_t stream)
+{
+    size_t n = (size_t)H * W, nb = align_up(n * 8, 256);
+    uint8_t *base = (uint8_t *)d_ws;
+    double *off = (double *)base, *offc = (double *)(base + nb), *tmpA = (double *)(base + 2 * nb), *tmpB = (double *)(base + 3 * nb);
+    uint8_t *target = base + 4 * nb;
+    uint16_t *hd = (uint16_t *)(target + align_up(n, 256));
+    int R1 = gauss_radius(sigma1), R2 = gauss_radius(sigma2);
+    double *w1 = (double *)((uint8_t *)hd + align_up(n * 2, 256));
+    double *w2 = w1 + (2 * R1 + 1);
+    double *partial = (double *)((uint8_t *)w1 + align_up((2 * R1 + 1 + 2 * R2 + 1) * 8, 256));
+    double *scal = partial + 1024;
+    int *any = (int *)(scal + 8);
+    // weights: computed on the host exactly as SciPy does, then copied (small, pageable -> staged synchronously by HIP)
+    static thread_local double *hw = nullptr; static thread_local size_t hw_cap = 0;
+    size_t nw = (size_t)(2 * R1 + 1 + 2 * R2 + 1);
+    if (hw_cap < nw) { free(hw); hw = (double *)malloc(nw * 8); hw_cap = nw; }
+    sdsm_gauss_kernel_host(sigma1, R1, hw);
+    sdsm_gauss_kernel_host(sigma2, R2, hw + 2 * R1 + 1);
+    hipError_t e = hipMemcpyAsync(w1, hw, nw * 8, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(scal, 0, 128, stream);
+    if (e != hipSuccess) return e;
+    const int use_clip = !std::isinf(offset_clip);
+    dim3 b(256), g1((n + 255) / 256), g2((W + 255) / 256, H);
+    int npart = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    e = gauss2d(d_g, H, W, w2, R2, tmpA, off, stream);                                       // offset_original (:47)
+    if (e != hipSuccess) return e;
+    if (use_clip || lower_clip_mean) {
+        hipLaunchKernelGGL(k_partial, dim3(npart), b, 0, stream, d_g, n, 0, (const double *)scal, partial);
+        hipLaunchKernelGGL(k_final, dim3(1), b, 0, stream, (const double *)partial, npart, (double)n, 0, offset_clip, scal);
+    }
+    if (use_clip) {
+        hipLaunchKernelGGL(k_partial, dim3(npart), b, 0, stream, d_g, n, 1, (const double *)scal, partial);
+        hipLaunchKernelGGL(k_final, dim3(1), b, 0, stream, (const double *)partial, npart, (double)n, 1, offset_clip, scal);
+        hipLaunchKernelGGL(k_clip, g1, b, 0, stream, d_g, n, (const double *)scal, tmpB);
+        e = gauss2d(tmpB, H, W, w2, R2, tmpA, offc, stream);                                 // offset_clipped (:53)
+        if (e != hipSuccess) return e;
+        int radius = (int)ceil(sigma2);
+        hipLaunchKernelGGL(k_target, g1, b, 0, stream, d_g, n, 1, (const double *)scal, target, any);
+        hipLaunchKernelGGL(k_hdist, g2, b, 0, stream, (const uint8_t *)target, H, W, radius, hd);
+        hipLaunchKernelGGL(k_vdist, g2, b, 0, stream, (const uint16_t *)hd, H, W, radius, (const int *)any, 0.0,
+                           (const uint8_t *)nullptr, (uint8_t *)nullptr, sigma2, tmpB);      // t = max(sigma2 - d, 0)
+    }
+    // denoised image into tmpA via d_y as the intermediate
+    e = gauss2d(d_g, H, W, w1, R1, d_y, tmpA, stream);                                       // gauss(g, sigma1) (:64)
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_combine, g1, b, 0, stream, (const double *)tmpA, (const double *)off, (const double *)offc, (const double *)tmpB,
+                       n, use_clip, lower_clip_mean, (const double *)scal, (const int *)any, sigma2, d_y);
+    return hipGetLastError();
+}

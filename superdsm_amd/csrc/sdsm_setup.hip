@@ -1,0 +1,283 @@
+// Candidate setup: region crop, compressed coordinates, greedy sub-sample grid, G~ rows (ELL).
+// One 256-thread workgroup per candidate.
+//
+// Reference behaviour restated here (never its code):
+//   region        superdsm/objects.py:93,126-127  in1d(atoms, footprint) & y_mask & (EDT(y<=0) <= margin)
+//                 (the candidate-independent part `valid` comes from sdsm_image_prepare)
+//   trivial rule  superdsm/objects.py:184-191
+//   mask compression, "too small" rule       superdsm/dsm.py:185-187
+//   greedy grid   superdsm/dsm.py:164-181
+//   PSF gather + float32 row normalisation   superdsm/dsm.py:145-161,192-193,232
+#include "sdsm_common.h"
+
+namespace {
+
+struct WeightCtx {
+    int cr, cc, R, k;
+    const float *psf;
+    const uint32_t *keys;   // sorted grid keys in LDS
+    uint16_t *ell_idx;
+    float *ell_w;
+    int64_t base;           // ell_off + pixel
+    int N, zcap, nnz;
+    bool overflow;
+};
+
+__device__ __forceinline__ float wval(WeightCtx &c, int j)
+{
+    uint32_t key = c.keys[j];
+    int dr = (int)(key >> 16) - c.cr, dc = (int)(key & 0xffffu) - c.cc;
+    int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
+    if (adr <= c.R && adc <= c.R) {
+        float v = c.psf[(c.R + dr) * c.k + (c.R + dc)];
+        if (c.nnz < c.zcap) {
+            c.ell_idx[c.base + (int64_t)c.nnz * c.N] = (uint16_t)j;
+            c.ell_w[c.base + (int64_t)c.nnz * c.N] = v;
+        } else c.overflow = true;
+        c.nnz++;
+        return v;
+    }
+    return 0.f;
+}
+
+// numpy's pairwise float32 sum of one block of <= 128 elements (loops_utils.h.src)
+__device__ float pw_block(WeightCtx &c, int lo, int n)
+{
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; i++) res += wval(c, lo + i);
+        return res;
+    }
+    float r0 = wval(c, lo), r1 = wval(c, lo + 1), r2 = wval(c, lo + 2), r3 = wval(c, lo + 3);
+    float r4 = wval(c, lo + 4), r5 = wval(c, lo + 5), r6 = wval(c, lo + 6), r7 = wval(c, lo + 7);
+    int nfull = n - (n % 8), i;
+    for (i = 8; i < nfull; i += 8) {
+        r0 += wval(c, lo + i); r1 += wval(c, lo + i + 1); r2 += wval(c, lo + i + 2); r3 += wval(c, lo + i + 3);
+        r4 += wval(c, lo + i + 4); r5 += wval(c, lo + i + 5); r6 += wval(c, lo + i + 6); r7 += wval(c, lo + i + 7);
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += wval(c, lo + i);
+    return res;
+}
+
+// full pairwise recursion (n > 128 splits at n/2 rounded down to a multiple of 8), iteratively
+__device__ float pw_sum(WeightCtx &c, int M)
+{
+    if (M <= 128) return pw_block(c, 0, M);
+    int s_lo[16], s_n[16], s_stage[16];
+    float s_left[16];
+    int sp = 0;
+    s_lo[0] = 0; s_n[0] = M; s_stage[0] = 0; s_left[0] = 0.f;
+    float ret = 0.f;
+    while (sp >= 0) {
+        if (s_n[sp] <= 128) { ret = pw_block(c, s_lo[sp], s_n[sp]); sp--; continue; }
+        int n2 = s_n[sp] / 2; n2 -= n2 % 8;
+        if (s_stage[sp] == 0) {
+            s_stage[sp] = 1;
+            s_lo[sp + 1] = s_lo[sp]; s_n[sp + 1] = n2; s_stage[sp + 1] = 0; sp++;
+        } else if (s_stage[sp] == 1) {
+            s_left[sp] = ret; s_stage[sp] = 2;
+            s_lo[sp + 1] = s_lo[sp] + n2; s_n[sp + 1] = s_n[sp] - n2; s_stage[sp + 1] = 0; sp++;
+        } else { ret = s_left[sp] + ret; sp--; }
+    }
+    return ret;
+}
+
+__device__ __forceinline__ int cheb(int r0, int c0, int r1, int c1)
+{
+    int a = r0 - r1, b = c0 - c1;
+    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+    return a > b ? a : b;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const double *__restrict__ y,
+                                                         const int32_t *__restrict__ atoms,
+                                                         const uint8_t *__restrict__ valid)
+{
+    __shared__ uint32_t fpbits[(SDSM_MAX_LABELS + 1) / 32];
+    __shared__ uint32_t rowbits[SDSM_MAX_BBOX_DIM / 32], colbits[SDSM_MAX_BBOX_DIM / 32];
+    __shared__ uint16_t rowrank[SDSM_MAX_BBOX_DIM], colrank[SDSM_MAX_BBOX_DIM];
+    __shared__ uint32_t gridkeys[SDSM_MAX_GRID];
+    __shared__ unsigned long long mom[4];
+    __shared__ unsigned long long scr64[SDSM_WAVES];
+    __shared__ int scr32[SDSM_WAVES];
+    __shared__ int sh_M, sh_npos, sh_err;
+
+    const int tid = threadIdx.x;
+    const int ci = P.order[blockIdx.x];
+    const CandDesc cd = P.cand[ci];
+    CandState *st = &P.state[ci];
+
+    if (cd.h > SDSM_MAX_BBOX_DIM || cd.w > SDSM_MAX_BBOX_DIM || cd.N <= 0) {
+        if (tid == 0) { CandState s = {}; s.status = cd.N <= 0 ? ST_ERROR : ST_UNSUPPORTED; *st = s; }
+        return;
+    }
+    for (int i = tid; i < (SDSM_MAX_LABELS + 1) / 32; i += SDSM_WG) fpbits[i] = 0;
+    for (int i = tid; i < SDSM_MAX_BBOX_DIM / 32; i += SDSM_WG) { rowbits[i] = 0; colbits[i] = 0; }
+    if (tid < 4) mom[tid] = 0;
+    if (tid == 0) { sh_M = 0; sh_npos = 0; sh_err = 0; }
+    __syncthreads();
+    for (int i = tid; i < cd.fp_len; i += SDSM_WG) {
+        int l = P.fp_labels[cd.fp_off + i];
+        if (l >= 1 && l <= SDSM_MAX_LABELS) atomicOr(&fpbits[l >> 5], 1u << (l & 31));
+    }
+    __syncthreads();
+
+    // ---- 1. region scan in raster order over the bounding box -> packed crop -------------------
+    const int area = cd.h * cd.w;
+    int running = 0;
+    unsigned long long m_r = 0, m_c = 0, m_rr = 0, m_cc = 0;
+    int npos = 0;
+    for (int base = 0; base < area; base += SDSM_WG) {
+        int i = base + tid;
+        bool flag = false;
+        int r = 0, c = 0;
+        double yv = 0;
+        if (i < area) {
+            r = i / cd.w; c = i - r * cd.w;
+            size_t p = (size_t)(cd.r0 + r) * P.W + (cd.c0 + c);
+            int a = atoms[p];
+            flag = a >= 1 && a <= SDSM_MAX_LABELS && ((fpbits[a >> 5] >> (a & 31)) & 1u) && valid[p];
+            if (flag) yv = y[p];
+        }
+        int total;
+        int pos = block_excl_count(flag, scr32, &total);
+        if (flag) {
+            int64_t o = cd.crop_off + running + pos;
+            if (running + pos < cd.N) {
+                P.crop_y[o] = yv;
+                P.crop_rc[o] = ((uint32_t)(cd.r0 + r) << 16) | (uint32_t)(cd.c0 + c);
+            }
+            atomicOr(&rowbits[r >> 5], 1u << (r & 31));
+            atomicOr(&colbits[c >> 5], 1u << (c & 31));
+            if (yv > 0) {
+                unsigned long long rr = cd.r0 + r, cc = cd.c0 + c;
+                npos++; m_r += rr; m_c += cc; m_rr += rr * rr; m_cc += cc * cc;
+            }
+        }
+        running += total;
+    }
+    if (npos) { atomicAdd(&sh_npos, npos); atomicAdd(&mom[0], m_r); atomicAdd(&mom[1], m_c); atomicAdd(&mom[2], m_rr); atomicAdd(&mom[3], m_cc); }
+    __syncthreads();
+
+    // ---- 2. compressed coordinates: delete empty rows / columns (dsm.py:185-186) ---------------
+    for (int r = tid; r < cd.h; r += SDSM_WG) {
+        int cnt = 0;
+        for (int wd = 0; wd < (r >> 5); wd++) cnt += __popc(rowbits[wd]);
+        cnt += __popc(rowbits[r >> 5] & ((1u << (r & 31)) - 1u));
+        rowrank[r] = (uint16_t)cnt;
+    }
+    for (int c = tid; c < cd.w; c += SDSM_WG) {
+        int cnt = 0;
+        for (int wd = 0; wd < (c >> 5); wd++) cnt += __popc(colbits[wd]);
+        cnt += __popc(colbits[c >> 5] & ((1u << (c & 31)) - 1u));
+        colrank[c] = (uint16_t)cnt;
+    }
+    int hc = 0, wc = 0;
+    for (int wd = 0; wd < (cd.h + 31) / 32; wd++) hc += __popc(rowbits[wd]);
+    for (int wd = 0; wd < (cd.w + 31) / 32; wd++) wc += __popc(colbits[wd]);
+    __syncthreads();
+
+    CandState s = {};
+    s.hc = hc; s.wc = wc; s.npos = sh_npos;
+    s.sum_r = mom[0]; s.sum_c = mom[1]; s.sum_rr = mom[2]; s.sum_cc = mom[3];
+    if (running != cd.N) { s.status = ST_ERROR; if (tid == 0) *st = s; return; }          // plan / image mismatch
+    if (s.npos == 1) { s.status = ST_TRIVIAL; if (tid == 0) *st = s; return; }            // objects.py:184-191
+
+    const int S = P.subsample, R = P.R;
+    const bool null_matrix = P.no_deform || hc <= P.k / 2 || wc <= P.k / 2;               // dsm.py:187,225
+    for (int i = tid; i < cd.N; i += SDSM_WG) {
+        uint32_t rc = P.crop_rc[cd.crop_off + i];
+        int r = (int)(rc >> 16) - cd.r0, c = (int)(rc & 0xffffu) - cd.c0;
+        uint32_t key = ((uint32_t)rowrank[r] << 16) | (uint32_t)colrank[c];
+        P.crop_cc[cd.crop_off + i] = key;
+        if (null_matrix) P.ell_nnz[cd.crop_off + i] = 0;
+        else if (rowrank[r] % S == 0 && colrank[c] % S == 0) {                             // dsm.py:165-168
+            int j = atomicAdd(&sh_M, 1);
+            if (j < SDSM_MAX_GRID) gridkeys[j] = key;
+        }
+    }
+    if (null_matrix) { s.M = 0; s.status = ST_OK; if (tid == 0) *st = s; return; }
+    __syncthreads();
+    const int cap = cd.Mcap < SDSM_MAX_GRID ? cd.Mcap : SDSM_MAX_GRID;
+    int M = sh_M;
+    if (M > cap) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
+
+    // ---- 3. greedy completion of the grid (dsm.py:169-181) --------------------------------------
+    for (int i = tid; i < cd.N; i += SDSM_WG) {
+        uint32_t key = P.crop_cc[cd.crop_off + i];
+        int r = key >> 16, c = key & 0xffffu;
+        uint32_t d = 0xffffffffu;                       // distance_transform_bf without any grid point
+        for (int j = 0; j < M; j++) {
+            uint32_t t = (uint32_t)cheb(r, c, gridkeys[j] >> 16, gridkeys[j] & 0xffffu);
+            d = t < d ? t : d;
+        }
+        P.dist[cd.crop_off + i] = d;
+    }
+    bool unsupported = false;
+    for (;;) {
+        // smallest distance >= subsample; ties -> first pixel in raster order of the compressed mask
+        unsigned long long best = ~0ull;
+        for (int i = tid; i < cd.N; i += SDSM_WG) {
+            uint32_t d = P.dist[cd.crop_off + i];
+            if (d >= (uint32_t)S) {
+                unsigned long long key = ((unsigned long long)d << 32) | P.crop_cc[cd.crop_off + i];
+                best = key < best ? key : best;
+            }
+        }
+        best = block_min_u64(best, scr64);
+        if (best == ~0ull) break;
+        if (M >= cap) { unsupported = true; break; }
+        uint32_t nk = (uint32_t)(best & 0xffffffffull);
+        if (tid == 0) gridkeys[M] = nk;
+        M++;
+        int nr = nk >> 16, nc = nk & 0xffffu;
+        for (int i = tid; i < cd.N; i += SDSM_WG) {
+            uint32_t key = P.crop_cc[cd.crop_off + i];
+            uint32_t t = (uint32_t)cheb(key >> 16, key & 0xffffu, nr, nc);
+            if (t < P.dist[cd.crop_off + i]) P.dist[cd.crop_off + i] = t;
+        }
+    }
+    if (unsupported) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
+    __syncthreads();
+
+    // ---- 4. columns of G~ = grid points in raster order (np.nonzero(col_mask), dsm.py:159) ------
+    for (int j = tid; j < M; j += SDSM_WG) {
+        uint32_t key = gridkeys[j];
+        int rank = 0;
+        for (int q = 0; q < M; q++) rank += gridkeys[q] < key;
+        P.grid_rc[cd.xi_off + rank] = key;
+    }
+    __syncthreads();
+    for (int j = tid; j < M; j += SDSM_WG) gridkeys[j] = P.grid_rc[cd.xi_off + j];
+    __syncthreads();
+
+    // ---- 5. rows of G~: PSF gather, float32 pairwise row sum, float32 division (dsm.py:192-193) --
+    bool bad = false;
+    for (int i = tid; i < cd.N; i += SDSM_WG) {
+        uint32_t key = P.crop_cc[cd.crop_off + i];
+        WeightCtx c;
+        c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.keys = gridkeys;
+        c.ell_idx = P.ell_idx; c.ell_w = P.ell_w; c.base = cd.ell_off + i; c.N = cd.N; c.zcap = P.zcap; c.nnz = 0; c.overflow = false;
+        float sum = pw_sum(c, M);
+        if (c.overflow || !(sum > 0.f)) { bad = true; P.ell_nnz[cd.crop_off + i] = 0; continue; }   // dsm.py:194
+        for (int sl = 0; sl < c.nnz; sl++) {
+            int64_t e = c.base + (int64_t)sl * cd.N;
+            P.ell_w[e] = __fdiv_rn(P.ell_w[e], sum);
+        }
+        P.ell_nnz[cd.crop_off + i] = (uint16_t)c.nnz;
+    }
+    if (bad) atomicOr(&sh_err, 1);
+    __syncthreads();
+    s.M = M;
+    s.status = sh_err ? ST_ERROR : ST_OK;
+    if (tid == 0) *st = s;
+}
+
+extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sdsm_k_setup, dim3(P.n), dim3(SDSM_WG), 0, stream, P, d_y, d_atoms, d_valid);
+    return hipGetLastError();
+}

@@ -1,0 +1,189 @@
+"""Device-side engine: thin Python over the C ABI (include/sdsm.h).
+
+PyTorch-ROCm tensors own every device buffer; their ``data_ptr()`` and the current stream's handle are passed
+to libsdsm_hip.so.  Nothing here computes on the CPU: if the HIP library or a GPU is missing, construction
+fails loudly.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _capi.SdsmError('no HIP device available: the DSM solve path has no CPU fallback')
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def preprocess(g_raw, sigma1=np.sqrt(2), sigma2=40, offset_clip=3, lower_clip_mean=False, device=None, return_tensor=False):
+    """Offset-intensity map ``y`` (reference: Preprocessing.process, superdsm/preprocess.py:39-68)."""
+    _require_gpu()
+    L = _capi.lib()
+    dev = torch.device(device if device is not None else 'cuda')
+    g = torch.as_tensor(np.ascontiguousarray(g_raw, dtype=np.float64)).to(dev) if not torch.is_tensor(g_raw) else g_raw.to(dev, torch.float64).contiguous()
+    H, W = g.shape
+    y = torch.empty_like(g)
+    nbytes = L.sdsm_preprocess_workspace_bytes(H, W, float(sigma1), float(sigma2))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _capi.check(L.sdsm_preprocess(_ptr(g), H, W, float(sigma1), float(sigma2), float(offset_clip), int(bool(lower_clip_mean)),
+                                      _ptr(y), _ptr(ws), nbytes, _stream()), 'sdsm_preprocess')
+    return y if return_tensor else y.cpu().numpy()
+
+
+class DeviceImage:
+    """Per-image device state: y, atoms, the candidate-independent validity mask and per-atom extents.
+
+    Replaces the per-candidate O(H*W) work of Object.get_cvxprog_region (superdsm/objects.py:95-128): the EDT
+    term does not depend on the candidate and is evaluated once.
+    """
+
+    def __init__(self, y, y_mask, atoms, background_margin, device=None):
+        _require_gpu()
+        L = _capi.lib()
+        self.device = torch.device(device if device is not None else 'cuda')
+        as_dev = lambda a, dt: (a.to(self.device, dt).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(self.device))
+        self.y = as_dev(y, torch.float64 if torch.is_tensor(y) else np.float64)
+        self.atoms = as_dev(atoms, torch.int32 if torch.is_tensor(atoms) else np.int32)
+        self.y_mask = None if y_mask is None else as_dev(y_mask, torch.uint8 if torch.is_tensor(y_mask) else np.uint8)
+        self.H, self.W = (int(v) for v in self.y.shape)
+        assert tuple(self.atoms.shape) == (self.H, self.W)
+        self.background_margin = float(background_margin)
+        self.n_atoms = int(self.atoms.max().item()) if self.atoms.numel() else 0
+        self.valid = torch.empty((self.H, self.W), dtype=torch.uint8, device=self.device)
+        stats = torch.empty(((self.n_atoms + 1) * _capi.ATOM_STATS_STRIDE,), dtype=torch.int32, device=self.device)
+        nbytes = L.sdsm_image_workspace_bytes(self.H, self.W)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(L.sdsm_image_prepare(_ptr(self.y), _ptr(self.y_mask), _ptr(self.atoms), self.H, self.W, self.background_margin,
+                                             self.n_atoms, _ptr(self.valid), _ptr(stats), _ptr(ws), nbytes, _stream()), 'sdsm_image_prepare')
+        self.atom_stats = np.ascontiguousarray(stats.cpu().numpy())       # host copy used by the planner (synchronises)
+
+
+class Batch:
+    """One ``compute_objects`` call: plan, workspace, launch, results."""
+
+    def __init__(self, image, footprints, dsm_cfg, want_xi=False):
+        L = _capi.lib()
+        self.image = image
+        self.n = len(footprints)
+        self.footprints = [sorted(int(a) for a in fp) for fp in footprints]
+        offs = np.zeros(self.n + 1, np.int32)
+        offs[1:] = np.cumsum([len(fp) for fp in self.footprints])
+        labels = np.ascontiguousarray(np.concatenate(self.footprints) if self.n else np.zeros(0), dtype=np.int32)
+        self.cfg = _capi.make_config(dict(dsm_cfg, background_margin=image.background_margin))
+        self.plan = L.sdsm_plan_create(image.H, image.W, image.n_atoms, image.atom_stats.ctypes.data_as(C.c_void_p), C.byref(self.cfg),
+                                       self.n, offs.ctypes.data_as(C.c_void_p), labels.ctypes.data_as(C.c_void_p))
+        if not self.plan:
+            raise _capi.SdsmError('sdsm_plan_create failed: ' + L.sdsm_last_error().decode())
+        dev = image.device
+        self.ws_bytes = L.sdsm_plan_workspace_bytes(self.plan)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.records_dev = torch.zeros(max(self.n, 1) * _capi.RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self.mask_bytes = L.sdsm_plan_mask_bytes(self.plan)
+        self.masks_dev = torch.empty(self.mask_bytes, dtype=torch.uint8, device=dev)
+        self.xi_dev = torch.zeros(L.sdsm_plan_xi_count(self.plan), dtype=torch.float64, device=dev) if want_xi else None
+        self.mask_info = np.zeros((max(self.n, 1), 4), np.int32)
+        self.mask_offset = np.zeros(max(self.n, 1), np.int64)
+        self.n_pixels = np.zeros(max(self.n, 1), np.int32)
+        _capi.check(L.sdsm_plan_describe(self.plan, self.mask_info.ctypes.data_as(C.c_void_p), self.mask_offset.ctypes.data_as(C.c_void_p),
+                                         self.n_pixels.ctypes.data_as(C.c_void_p)), 'sdsm_plan_describe')
+        self.total_pixels = L.sdsm_plan_total_pixels(self.plan)
+        with torch.cuda.device(dev):
+            _capi.check(L.sdsm_batch_upload(self.plan, _ptr(self.ws), self.ws_bytes, _stream()), 'sdsm_batch_upload')
+
+    def __del__(self):
+        plan = getattr(self, 'plan', None)
+        if plan:
+            _capi.lib().sdsm_plan_destroy(plan)
+            self.plan = None
+
+    def launch(self):
+        """Queues the setup and solve kernels on the current stream (asynchronous)."""
+        L = _capi.lib()
+        im = self.image
+        with torch.cuda.device(im.device):
+            _capi.check(L.sdsm_batch_launch(self.plan, _ptr(im.y), _ptr(im.atoms), _ptr(im.valid), _ptr(self.ws), self.ws_bytes,
+                                            _ptr(self.records_dev), _ptr(self.masks_dev), _ptr(self.xi_dev), _stream()), 'sdsm_batch_launch')
+
+    def records(self):
+        return self.records_dev.cpu().numpy().view(_capi.RECORD_DTYPE)[:self.n].copy()
+
+    def xi_offsets(self):
+        off = np.zeros(max(self.n, 1), np.int64)
+        _capi.check(_capi.lib().sdsm_plan_xi_offsets(self.plan, off.ctypes.data_as(C.c_void_p)), 'sdsm_plan_xi_offsets')
+        return off
+
+    def inspect(self):
+        """Setup-phase outputs for parity tests: per candidate (N, M, status, pixel coordinates, grid points,
+        CSR-like G~ rows).  Reads the workspace back to the host."""
+        lay = np.zeros(16, np.int64)
+        _capi.check(_capi.lib().sdsm_plan_layout(self.plan, lay.ctypes.data_as(C.c_void_p)), 'sdsm_plan_layout')
+        ws = self.ws.cpu().numpy()
+        zcap, npix, nell = int(lay[9]), int(lay[12]), int(lay[13])
+        state = ws[lay[1]:lay[1] + 64 * self.n].view(np.int32).reshape(self.n, 16)
+        crop_y = ws[lay[2]:lay[2] + 8 * npix].view(np.float64)
+        crop_rc = ws[lay[3]:lay[3] + 4 * npix].view(np.uint32)
+        crop_cc = ws[lay[4]:lay[4] + 4 * npix].view(np.uint32)
+        ell_nnz = ws[lay[5]:lay[5] + 2 * npix].view(np.uint16)
+        xi_off = self.xi_offsets()
+        grid = ws[lay[6]:].view(np.uint32)
+        ell_idx = ws[lay[7]:lay[7] + 2 * nell].view(np.uint16)
+        ell_w = ws[lay[8]:lay[8] + 4 * nell].view(np.float32)
+        out = []
+        po = 0
+        for i in range(self.n):
+            N = int(self.n_pixels[i])
+            M, status, hc, wc, npos = (int(v) for v in state[i, :5])
+            rc = crop_rc[po:po + N]
+            cc = crop_cc[po:po + N]
+            g = grid[xi_off[i]:xi_off[i] + M]
+            eo = po * zcap
+            nnz = ell_nnz[po:po + N].astype(np.int64)
+            idx = ell_idx[eo:eo + N * zcap].reshape(zcap, N) if N else np.zeros((zcap, 0), np.uint16)
+            w = ell_w[eo:eo + N * zcap].reshape(zcap, N) if N else np.zeros((zcap, 0), np.float32)
+            out.append(dict(N=N, M=M, status=status, hc=hc, wc=wc, npos=npos, y=crop_y[po:po + N].copy(),
+                            r=(rc >> 16).astype(np.int64), c=(rc & 0xffff).astype(np.int64),
+                            cr=(cc >> 16).astype(np.int64), cc=(cc & 0xffff).astype(np.int64),
+                            grid_r=(g >> 16).astype(np.int64), grid_c=(g & 0xffff).astype(np.int64), nnz=nnz, idx=idx.copy(), w=w.copy()))
+            po += N
+        return out
+
+    def fragments(self, records, select=None):
+        """Foreground fragments (bool arrays) and offsets, cropped from the bit-packed region-bbox masks."""
+        masks = self.masks_dev.cpu().numpy()
+        out = []
+        for i in range(self.n):
+            if select is not None and not select[i]:
+                out.append((None, None))
+                continue
+            r = records[i]
+            if r['fg_h'] <= 0 or r['status'] in (_capi.CAND_TRIVIAL, _capi.CAND_ERROR):
+                out.append((np.zeros(2, int), np.zeros((1, 1), bool)))        # objects.py:172-174, 185-186
+                continue
+            r0, c0, h, w = (int(v) for v in self.mask_info[i])
+            nbytes = ((h * w + 31) // 32) * 4
+            bits = np.unpackbits(masks[self.mask_offset[i]:self.mask_offset[i] + nbytes], bitorder='little')[:h * w].reshape(h, w)
+            fr, fc = int(r['fg_r0']) - r0, int(r['fg_c0']) - c0
+            frag = bits[fr:fr + int(r['fg_h']), fc:fc + int(r['fg_w'])].astype(bool)
+            out.append((np.array([int(r['fg_r0']), int(r['fg_c0'])]), frag))
+        return out
+
+
+def algorithmic_bytes(records, mask_info):
+    """bytes_c = E_c (12 N_c + 8 (6 + M_c)) + 12 N_c + ceil(bbox_c / 8) + 128."""
+    E = records['evals_value'].astype(np.int64) + records['evals_full'].astype(np.int64)
+    N = records['n_pixels'].astype(np.int64)
+    M = records['n_deform'].astype(np.int64)
+    bbox = (mask_info[:len(records), 2].astype(np.int64) * mask_info[:len(records), 3].astype(np.int64) + 7) // 8
+    return int((E * (12 * N + 8 * (6 + M)) + 12 * N + bbox + 128).sum())

@@ -150,3 +150,22 @@ WORKLOADS = {
     'nih3t3_like':  dict(shape=(1344, 1024), n=48, radius=43, seed=1004, scale=40),
     'synthetic4096': dict(shape=(4096, 4096), n=2000, radius=15, seed=1005, scale=10),
 }
+
+
+def offset_image(g, sigma2, sigma1=math.sqrt(2), offset_clip=3):
+    """Offset intensities y of a synthetic image via SciPy (test-data generation; same formula as the
+    reference's preprocessing, superdsm/preprocess.py:42-64, so that scenes can be built without a GPU)."""
+    off = ndi.gaussian_filter(g, sigma2)
+    clip_abs = offset_clip * g.std()
+    offc = ndi.gaussian_filter(g.clip(0, clip_abs), sigma2)
+    t = ndi.distance_transform_edt(~(g > clip_abs))
+    t = (sigma2 - t).clip(0, np.inf)
+    t = (t / t.max()) ** 2
+    return ndi.gaussian_filter(g, sigma1) - ((1 - t) * offc + t * off)
+
+
+def dsm_config_for_scale(scale, alpha_factor=0.0005):
+    """AF_ rule of the reference (superdsm/automation.py:71-77 with the factors of dsmcfg.py:91-97)."""
+    return dict(scale=1000, epsilon=1.0, alpha=scale ** 2 * alpha_factor, smooth_amount=max(4, int(scale * 0.2)),
+                smooth_subsample=max(8, int(scale * 0.4)), gaussian_shape_multiplier=2, background_margin=max(8, int(scale * 0.4)),
+                init='elliptical')

@@ -1,0 +1,245 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden fixtures.  Needs an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def unpack(bits, shape):
+    shape = tuple(int(s) for s in shape)
+    return np.unpackbits(bits)[:int(np.prod(shape))].reshape(shape).astype(bool)
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), 'these tests need a GPU'
+    from superdsm_amd import _capi
+    _capi.lib()     # fails loudly if libsdsm_hip.so is missing
+    return torch
+
+
+def _golden_scene(tag):
+    d = np.load(os.path.join(G, f'optimum_{tag}.npz'))
+    cfg = json.loads(str(d['cfg']))
+    fps = [d[f'c{k}_fp'].tolist() for k in range(int(d['n_cases']))]
+    return d, dict(cfg, init='elliptical'), fps
+
+
+# ---------------------------------------------------------------------------------------------------------
+# per-image preparation: EDT(y <= 0) <= margin, atom extents (objects.py:126-127)
+# ---------------------------------------------------------------------------------------------------------
+def test_image_prepare_matches_oracle(gpu):
+    from oracle import oracle
+    from superdsm_amd import engine
+    d = np.load(os.path.join(G, 'region.npz'))
+    shape = tuple(int(v) for v in d['shape'])
+    y, atoms = d['y'], d['atoms']
+    y_mask = unpack(d['y_mask'], shape)
+    for margin in (3, 8, 2.5):
+        img = engine.DeviceImage(y, y_mask, atoms, margin)
+        valid = img.valid.cpu().numpy().astype(bool)
+        expect = y_mask & (oracle.edt_sq(y <= 0) <= margin * margin)
+        np.testing.assert_array_equal(valid, expect)
+        stats = img.atom_stats.reshape(-1, 6)
+        for l in range(1, int(atoms.max()) + 1):
+            m = expect & (atoms == l)
+            assert stats[l, 0] == m.sum()
+            if m.any():
+                rr, cc = np.nonzero(m)
+                assert tuple(stats[l, 1:5]) == (rr.min(), rr.max(), cc.min(), cc.max())
+    np.testing.assert_array_equal(engine.DeviceImage(y, None, atoms, 8).valid.cpu().numpy().astype(bool), unpack(d['edt_le_8'], shape))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# setup kernel: region crops, greedy grid, float32-exact G~ rows (dsm.py:137-237)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma'])
+def test_setup_matches_oracle_exactly(gpu, tag):
+    from oracle import oracle
+    from superdsm_amd import engine
+    d, cfg, fps = _golden_scene(tag)
+    y, atoms = d['y'], d['atoms']
+    img = engine.DeviceImage(y, None, atoms, cfg['background_margin'])
+    batch = engine.Batch(img, fps, cfg)
+    batch.launch()
+    gpu.cuda.synchronize()
+    info = batch.inspect()
+    for k, fp in enumerate(fps):
+        mask = oracle.region_mask(y, None, atoms, fp, cfg['background_margin'])
+        np.testing.assert_array_equal(mask, unpack(d[f'c{k}_region'], y.shape))
+        s = info[k]
+        rr, cc = np.nonzero(mask)                       # raster order
+        assert s['N'] == mask.sum() == int(d[f'c{k}_N'])
+        np.testing.assert_array_equal(s['r'], rr)
+        np.testing.assert_array_equal(s['c'], cc)
+        np.testing.assert_array_equal(s['y'], y[mask])
+        sm = oracle.smooth_matrix(mask, cfg['smooth_amount'], cfg['gaussian_shape_multiplier'], cfg['smooth_subsample'])
+        assert s['M'] == sm.M == int(d[f'c{k}_M'])
+        assert (s['hc'], s['wc']) == sm.compressed_shape
+        np.testing.assert_array_equal(s['grid_r'], sm.grid_r)
+        np.testing.assert_array_equal(s['grid_c'], sm.grid_c)
+        nnz = np.diff(sm.indptr)
+        np.testing.assert_array_equal(s['nnz'], nnz)
+        for i in range(0, s['N'], 7):                   # every 7th row, all entries: indices and float32-exact weights
+            lo, hi = sm.indptr[i], sm.indptr[i + 1]
+            np.testing.assert_array_equal(s['idx'][:nnz[i], i], sm.indices[lo:hi])
+            np.testing.assert_array_equal(s['w'][:nnz[i], i].astype(np.float64), sm.data[lo:hi])
+
+
+@pytest.mark.parametrize('name', ['blob', 'two_blobs_gaps', 'too_small', 'no_regular_grid_point', 'dense_grid_m_gt_128', 'l_shape', 'gowt1_like', 'odd_params'])
+def test_setup_matches_reference_smooth_matrix(gpu, name):
+    """G~ of the reference itself (golden CSR) for hand-made masks, including the edge cases: empty rows/cols
+    inside the bbox, region too small for the PSF, no regular grid point inside the mask, M > 128 (numpy's
+    pairwise float32 summation splits)."""
+    from superdsm_amd import engine
+    d = np.load(os.path.join(G, f'smoothmat_{name}.npz'))
+    mask = unpack(d['mask'], d['mask_shape'])
+    sigma, mult, sub = d['params']
+    H, W = mask.shape[0] + 6, mask.shape[1] + 9
+    atoms = np.zeros((H, W), np.int32)
+    atoms[3:3 + mask.shape[0], 4:4 + mask.shape[1]][mask] = 1
+    atoms[atoms == 0] = 2
+    y = np.where(atoms == 1, 1.0, -1.0)               # every region pixel is foreground -> EDT term is 0 there
+    cfg = dict(scale=1000, epsilon=1.0, alpha=0.01, smooth_amount=float(sigma), smooth_subsample=int(sub),
+               gaussian_shape_multiplier=float(mult), background_margin=0, init='elliptical', max_iters=1)
+    img = engine.DeviceImage(y, None, atoms, 0)
+    batch = engine.Batch(img, [[1]], cfg)
+    batch.launch()
+    gpu.cuda.synchronize()
+    s = batch.inspect()[0]
+    N, M = (int(v) for v in d['shape'])
+    assert (s['N'], s['M']) == (N, M)
+    if M == 0:
+        return
+    grid = np.zeros((s['hc'], s['wc']), bool)
+    grid[s['grid_r'], s['grid_c']] = True
+    np.testing.assert_array_equal(grid, unpack(d['grid'], d['grid_shape']))
+    indptr, indices, data = d['indptr'], d['indices'], d['data']
+    np.testing.assert_array_equal(s['nnz'], np.diff(indptr))
+    got_idx = np.concatenate([s['idx'][:s['nnz'][i], i] for i in range(N)])
+    got_w = np.concatenate([s['w'][:s['nnz'][i], i] for i in range(N)]).astype(np.float64)
+    np.testing.assert_array_equal(got_idx, indices)
+    np.testing.assert_array_equal(got_w, data)       # float32-exact
+
+
+# ---------------------------------------------------------------------------------------------------------
+# solves: tight optima of the reference's energy, masks, boundary flag
+# ---------------------------------------------------------------------------------------------------------
+def _paste(off, frag, shape):
+    out = np.zeros(shape, bool)
+    out[off[0]:off[0] + frag.shape[0], off[1]:off[1] + frag.shape[1]] = frag
+    return out
+
+
+@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma'])
+def test_solve_reaches_reference_optima(gpu, tag):
+    from oracle import oracle
+    from superdsm_amd import _capi, testing
+    d, cfg, fps = _golden_scene(tag)
+    scene = dict(y=d['y'], atoms=d['atoms'], dsm_cfg=cfg, footprints=fps)
+    res = testing.solve_scene_gpu(scene, want_xi=True)
+    recs, frags = res['records'], res['fragments']
+    orecs, ofrags, oparams = oracle.compute_objects(d['y'], None, d['atoms'], fps, cfg, nthreads=0)
+    for k in range(len(fps)):
+        N, M = int(d[f'c{k}_N']), int(d[f'c{k}_M'])
+        assert (recs['n_pixels'][k], recs['n_deform'][k]) == (N, M)
+        psi_ref = float(d[f'c{k}_psi_dsm'])
+        tol = 1e-6 * N / 1000 + 1e-5 * abs(psi_ref)          # fp tolerance on energies
+        tight = float(d[f'c{k}_gnorm_dsm']) < 1e-8 and float(d[f'c{k}_gnorm_ell']) < 1e-8
+        # the energy the kernel reports is the reference's energy function at the kernel's own parameters
+        mask = oracle.region_mask(d['y'], None, d['atoms'], fps[k], cfg['background_margin'])
+        J = oracle.Energy(d['y'], mask, cfg['epsilon'], cfg['alpha'], cfg['smooth_amount'], cfg['gaussian_shape_multiplier'], cfg['smooth_subsample'])
+        xo = res['xi_offsets'][k]
+        p = np.concatenate([recs['theta'][k], res['xi'][xo:xo + M]])
+        assert abs(J(p) - recs['energy'][k]) <= 1e-9 * max(1.0, abs(recs['energy'][k])), (k, J(p), recs['energy'][k])
+        if tight:
+            assert recs['status'][k] == _capi.CAND_OPTIMAL
+            assert abs(recs['energy'][k] - psi_ref) <= tol, (k, recs['energy'][k], psi_ref)
+            assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol
+            ref = _paste(d[f'c{k}_fg_offset'], unpack(d[f'c{k}_fg_fragment'], d[f'c{k}_fg_shape']), d['y'].shape)
+            got = _paste(*frags[k], d['y'].shape)
+            dice = 2 * (ref & got).sum() / max(1, ref.sum() + got.sum())
+            assert dice >= 0.999, (k, dice)
+            assert bool(recs['on_boundary'][k]) == bool(d[f'c{k}_on_boundary'])
+        else:
+            assert recs['energy'][k] <= psi_ref + tol          # near-separable: no finite minimiser
+
+
+def test_solve_matches_oracle_on_synthetic256(gpu):
+    """BASELINE.json configs[0]: 256x256 synthetic image, every candidate, GPU vs CPU oracle."""
+    from oracle import oracle
+    from superdsm_amd import testing
+    scene = testing.make_scene('synthetic256', max_size=3)
+    res = testing.solve_scene_gpu(scene)
+    recs, frags = res['records'], res['fragments']
+    orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], scene['footprints'], scene['dsm_cfg'], nthreads=0)
+    n = len(scene['footprints'])
+    np.testing.assert_array_equal(recs['n_pixels'], orecs['N'])
+    np.testing.assert_array_equal(recs['n_deform'], orecs['M'])
+    worst_dice = 1.0
+    for k in range(n):
+        assert recs['status'][k] == orecs['status'][k], (k, recs['status'][k], orecs['status'][k])
+        tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
+        assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (k, recs['energy'][k], orecs['energy'][k])
+        assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][k])
+        dice = testing.dice(frags[k][0], frags[k][1], orecs['fg_offset'][k], ofrags[k], scene['y'].shape)
+        worst_dice = min(worst_dice, dice)
+    assert worst_dice >= 0.999, worst_dice
+
+
+def test_full_size_properties_bbbc039_like(gpu):
+    """BASELINE.json configs[1] at full size: properties that do not need the CPU oracle on every candidate."""
+    from oracle import oracle
+    from superdsm_amd import _capi, testing
+    scene = testing.make_scene('bbbc039_like', max_size=3)
+    fps = scene['footprints']
+    res = testing.solve_scene_gpu(scene)
+    recs = res['records']
+    ok = recs['status'] == _capi.CAND_OPTIMAL
+    assert ok.mean() > 0.95
+    assert np.isfinite(recs['energy'][ok]).all() and (recs['energy'][ok] >= 0).all()
+    # the DSM can only improve on the elliptical model it starts from (monotone line search)
+    assert (recs['energy'][ok] <= recs['energy_ell'][ok] * (1 + 1e-9) + 1e-9).all()
+    # idempotence / determinism: a second launch of the same plan gives bit-identical records
+    res['batch'].launch()
+    gpu.cuda.synchronize()
+    recs2 = res['batch'].records()
+    for f in ('energy', 'theta', 'status', 'iters_dsm', 'fg_r0', 'fg_c0', 'fg_h', 'fg_w'):
+        np.testing.assert_array_equal(recs[f], recs2[f])
+    # permutation invariance: candidates are independent
+    perm = np.random.default_rng(0).permutation(len(fps))
+    res3 = testing.solve_scene_gpu(scene, footprints=[fps[i] for i in perm])
+    np.testing.assert_array_equal(res3['records']['energy'], recs['energy'][perm])
+    # fragments stay inside the region bounding box and contain only region pixels
+    img, batch = res['image'], res['batch']
+    for k in range(0, len(fps), 17):
+        off, frag = res['fragments'][k]
+        r0, c0, h, w = batch.mask_info[k]
+        if recs['fg_h'][k] > 0:
+            assert r0 <= off[0] and off[0] + frag.shape[0] <= r0 + h and c0 <= off[1] and off[1] + frag.shape[1] <= c0 + w
+            assert frag[0].any() and frag[-1].any() and frag[:, 0].any() and frag[:, -1].any()     # minimal bounding box
+    # spot check against the oracle on a subset (keeps the CPU time bounded)
+    sub = list(range(0, len(fps), 25))
+    orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], [fps[i] for i in sub], scene['dsm_cfg'], nthreads=0)
+    for j, k in enumerate(sub):
+        tol = 1e-6 * orecs['N'][j] / 1000 + 1e-5 * abs(orecs['energy'][j])
+        assert abs(recs['energy'][k] - orecs['energy'][j]) <= tol, (k, recs['energy'][k], orecs['energy'][j])
+        assert testing.dice(res['fragments'][k][0], res['fragments'][k][1], orecs['fg_offset'][j], ofrags[j], scene['y'].shape) >= 0.999
+
+
+# ---------------------------------------------------------------------------------------------------------
+# preprocessing (preprocess.py:39-68)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('key', ['a', 'b', 'c', 'd'])
+def test_preprocess_matches_reference(gpu, key):
+    from superdsm_amd import engine
+    d = np.load(os.path.join(G, f'preprocess_{key}.npz'))
+    cfg = json.loads(str(d['cfg']))
+    y = engine.preprocess(d['g_raw'], cfg.get('sigma1', np.sqrt(2)), cfg.get('sigma2', 40), cfg.get('offset_clip', 3), cfg.get('lower_clip_mean', False))
+    np.testing.assert_allclose(y, d['y'], rtol=0, atol=1e-13)     # tolerance: fp64 re-association in mean / std only
