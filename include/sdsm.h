@@ -150,6 +150,9 @@ int sdsm_plan_xi_offsets(const sdsm_plan *plan, int64_t *xi_offset);
 int sdsm_enable_kernel_timing(int enable);
 double sdsm_last_solve_kernel_ms(void);
 double sdsm_last_setup_kernel_ms(void);
+/* Diagnostic builds only (-DSDSM_PROFILE): device buffer receiving 8 int64 cycle counters per candidate
+ * (phase A, phase B, reductions, factor+solve, line search, total, elliptical total, reserved). */
+int sdsm_set_debug_buffer(void *d_buf);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsdsm_hip.so')
+LIB_PATH = os.environ.get('SDSM_HIP_LIB', os.path.join(_HERE, 'libsdsm_hip.so'))   # override: diagnostic builds only
 
 SDSM_OK = 0
 ATOM_STATS_STRIDE = 6
@@ -59,6 +59,7 @@ SYMBOLS = {
     'sdsm_enable_kernel_timing': (_i32, [_i32]),
     'sdsm_last_solve_kernel_ms': (_f64, []),
     'sdsm_last_setup_kernel_ms': (_f64, []),
+    'sdsm_set_debug_buffer': (_i32, [_vp]),
 }
 
 _lib = None
@@ -75,6 +76,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SdsmError(f'{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). '
                             'There is no CPU fallback for the DSM solve path.')
+        # PyTorch-ROCm owns the device memory and ships its own HIP runtime (same SONAME as /opt/rocm's): it must be
+        # loaded first so that this library binds to the SAME runtime instance instead of bringing up a second one.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported

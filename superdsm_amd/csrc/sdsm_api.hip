@@ -11,7 +11,8 @@
 
 #include "sdsm_common.h"
 
-extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream);
+extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
+                                        hipStream_t side1, hipStream_t side2, hipEvent_t *ev);
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
@@ -125,6 +126,22 @@ struct sdsm_plan {
 
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
+// Multiplier A ~ 0.618 N coprime to N defines the scatter "position q holds raster rank (q * A) mod N"; the setup
+// kernel needs the inverse map rank -> position, i.e. A^-1 mod N.
+static uint32_t perm_inverse(uint32_t N)
+{
+    if (N <= 2) return 1;
+    uint64_t A = (uint64_t)(0.6180339887498949 * N);
+    if (A < 1) A = 1;
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; };
+    while (gcd(A, N) != 1) A++;
+    // extended Euclid: A * x = 1 (mod N)
+    int64_t t = 0, newt = 1, r = N, newr = (int64_t)(A % N);
+    while (newr != 0) { int64_t q = r / newr; int64_t tmp = t - q * newt; t = newt; newt = tmp; tmp = r - q * newr; r = newr; newr = tmp; }
+    if (t < 0) t += N;
+    return (uint32_t)t;
+}
+
 extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t *atom_stats, const sdsm_dsm_config *cfg,
                                        int n, const int32_t *offsets, const int32_t *labels)
 {
@@ -172,7 +189,7 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
         c.xi_off = p->total_xi; p->total_xi += c.Mcap;
         c.mask_off = p->total_mask_words; p->total_mask_words += ((int64_t)c.h * c.w + 31) / 32;
         c.hsave_slot = (6 + c.Mcap > 84) ? (int32_t)p->n_hsave++ : -1;
-        c.pad = 0;
+        c.perm_inv = perm_inverse((uint32_t)std::max<long>(N, 1));
         p->mask_info[4 * i] = r0; p->mask_info[4 * i + 1] = c0; p->mask_info[4 * i + 2] = c.h; p->mask_info[4 * i + 3] = c.w;
         p->mask_off_bytes[i] = c.mask_off * 4; p->xi_off[i] = c.xi_off; p->n_pixels[i] = c.N;
     }
@@ -248,6 +265,14 @@ extern "C" int sdsm_batch_upload(const sdsm_plan *p, void *d_ws, size_t ws_bytes
     return SDSM_OK;
 }
 
+static thread_local long long *g_prof = nullptr;
+// Diagnostic builds (-DSDSM_PROFILE): device buffer of 8 int64 cycle counters per candidate, see DESIGN.md.
+extern "C" int sdsm_set_debug_buffer(void *d_buf) { g_prof = (long long *)d_buf; return SDSM_OK; }
+
+// side streams / fork-join events of the three solve classes (created on first use, per host thread)
+static thread_local hipStream_t g_side[2] = {nullptr, nullptr};
+static thread_local hipEvent_t g_fj[3] = {nullptr, nullptr, nullptr};
+
 static thread_local int g_timing = 0;
 static thread_local hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
 static thread_local int g_ev_valid = 0;
@@ -292,11 +317,16 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_nnz = (uint16_t *)(b + p->off_ell_nnz);
     P.psf = (const float *)(b + p->off_psf);
     P.hsave = (double *)(b + p->off_hsave); P.hsave_stride = SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2;
+    P.prof = g_prof;
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     if ((e = sdsm_launch_setup(P, d_y, d_atoms, d_valid, s)) != hipSuccess) return hipfail(e, "launch setup");
     if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s)) != hipSuccess) return hipfail(e, "launch solve");
+    if (!g_side[0]) {
+        for (int i = 0; i < 2; i++) if ((e = hipStreamCreateWithFlags(&g_side[i], hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
+        for (int i = 0; i < 3; i++) if ((e = hipEventCreateWithFlags(&g_fj[i], hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
+    }
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, g_side[0], g_side[1], g_fj)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }

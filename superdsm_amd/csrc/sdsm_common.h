@@ -4,6 +4,15 @@
 #include <stdint.h>
 #include "../../include/sdsm.h"
 
+// Explicit global address space for pointers that travel through structs / non-inlined functions: without it the
+// compiler falls back to flat_load, whose results can only be awaited with vmcnt(0) (one load in flight at a time).
+#define SDSM_GLOBAL __attribute__((address_space(1)))
+typedef const double SDSM_GLOBAL *g_cdouble_p;
+typedef double SDSM_GLOBAL *g_double_p;
+typedef const float SDSM_GLOBAL *g_cfloat_p;
+typedef const uint32_t SDSM_GLOBAL *g_cu32_p;
+typedef const uint16_t SDSM_GLOBAL *g_cu16_p;
+
 #define SDSM_WG 256
 #define SDSM_WAVES (SDSM_WG / 64)
 
@@ -12,6 +21,14 @@
 #define SDSM_MAX_BBOX_DIM 4096     // row / column rank tables in LDS
 #define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
 #define SDSM_MAX_N_SOLVE 172       // 6 + M handled by the largest solve class
+
+#ifdef SDSM_PROFILE
+#define PROF_NOW() ((long long)__builtin_readcyclecounter())
+#define PROF_ADD(slot, t0) do { long long _t = PROF_NOW(); prof_acc[slot] += _t - (t0); (t0) = _t; } while (0)
+#else
+#define PROF_NOW() 0ll
+#define PROF_ADD(slot, t0) do { } while (0)
+#endif
 
 enum { ST_OK = 0, ST_TRIVIAL = 2, ST_ERROR = 3, ST_UNSUPPORTED = 4 };
 
@@ -26,7 +43,7 @@ struct CandDesc {
     int32_t fp_off, fp_len; // footprint labels
     int32_t Mcap;       // upper bound of M
     int32_t hsave_slot; // slot in the global Hessian-copy pool (only candidates that may reach the in-place class), else -1
-    int32_t pad;
+    uint32_t perm_inv;  // crop position of the pixel with raster rank i is (i * perm_inv) mod N (low-discrepancy scatter)
 };
 
 // Written by the setup kernel.
@@ -35,7 +52,7 @@ struct CandState {
     int32_t status;     // ST_*
     int32_t hc, wc;     // shape of the mask after deleting empty rows / columns (dsm.py:185-186)
     int32_t npos;       // region pixels with y > 0
-    int32_t pad;
+    int32_t zmax;       // largest number of non-zeros in a row of G~
     unsigned long long sum_r, sum_c, sum_rr, sum_cc;   // moments of the y > 0 pixels (image coordinates)
     unsigned long long reserved;
 };
@@ -63,6 +80,7 @@ struct BatchParams {
     const float *psf;
     double *hsave;                     // per-candidate Hessian copy for the in-place class
     int64_t hsave_stride;
+    long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 8 cycle counters per candidate
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -86,6 +104,27 @@ __device__ __forceinline__ double block_sum(double v, double *scratch)
 #pragma unroll
     for (int i = 0; i < SDSM_WAVES; i++) r += scratch[i];
     return r;
+}
+
+// Sums K values over the workgroup with ONE barrier pair; results broadcast.  scratch: SDSM_WAVES * K doubles.
+template <int K>
+__device__ __forceinline__ void block_sum_vec(double (&v)[K], double *scratch)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) scratch[(threadIdx.x >> 6) * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double r = 0;
+#pragma unroll
+        for (int w = 0; w < SDSM_WAVES; w++) r += scratch[w * K + k];
+        v[k] = r;
+    }
 }
 
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, unsigned long long *scratch)

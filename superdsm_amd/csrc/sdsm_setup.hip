@@ -145,7 +145,9 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         int total;
         int pos = block_excl_count(flag, scr32, &total);
         if (flag) {
-            int64_t o = cd.crop_off + running + pos;
+            // crop position: low-discrepancy scatter of the raster rank (neighbouring positions are far apart in the
+            // image, which decorrelates the LDS atomics of the sparse Hessian accumulation in the solve kernel)
+            int64_t o = cd.crop_off + (int64_t)(((unsigned long long)(running + pos) * cd.perm_inv) % (unsigned long long)cd.N);
             if (running + pos < cd.N) {
                 P.crop_y[o] = yv;
                 P.crop_rc[o] = ((uint32_t)(cd.r0 + r) << 16) | (uint32_t)(cd.c0 + c);
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
 
     // ---- 5. rows of G~: PSF gather, float32 pairwise row sum, float32 division (dsm.py:192-193) --
     bool bad = false;
+    int zmax = 0;
     for (int i = tid; i < cd.N; i += SDSM_WG) {
         uint32_t key = P.crop_cc[cd.crop_off + i];
         WeightCtx c;
@@ -267,11 +270,17 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             int64_t e = c.base + (int64_t)sl * cd.N;
             P.ell_w[e] = __fdiv_rn(P.ell_w[e], sum);
         }
+        for (int sl = c.nnz; sl < P.zcap; sl++) {           // padding: index 0, weight 0 (fixed-trip loops in the solve kernel)
+            int64_t e = c.base + (int64_t)sl * cd.N;
+            P.ell_idx[e] = 0; P.ell_w[e] = 0.f;
+        }
         P.ell_nnz[cd.crop_off + i] = (uint16_t)c.nnz;
+        zmax = c.nnz > zmax ? c.nnz : zmax;
     }
     if (bad) atomicOr(&sh_err, 1);
+    zmax = -block_min_i32(-zmax, scr32);
     __syncthreads();
-    s.M = M;
+    s.M = M; s.zmax = zmax;
     s.status = sh_err ? ST_ERROR : ST_OK;
     if (tid == 0) *st = s;
 }

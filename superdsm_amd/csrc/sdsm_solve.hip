@@ -11,13 +11,17 @@
 // DESIGN.md ("Solver"), identical step for step to the oracle's orc_newton, but run in a centred and
 // scaled local polynomial basis (psi is invariant under affine re-parametrisation of theta).
 //
-// Work decomposition of one full evaluation (psi, gradient, Hessian):
-//   phase A  lane = pixel: coalesced read of the packed crop (y f64 + (row,col) u16x2) and of the pixel's
-//            ELL row of G~, S, exp/log, residual r and curvature weight d; the pixel's dense Jacobian row is
-//            staged in LDS (float32, column-major, conflict-free).
-//   phase B  lane = (4x4 Hessian tile, pixel slice): register-tiled accumulation of J^T diag(d) J and J^T r
-//            over the staged pixels in float64; slices are combined with wave shuffles.
-//   psi and the 6 polynomial gradient entries are reduced with wavefront shuffles + one LDS hop.
+// One full evaluation (psi, gradient, Hessian) of a candidate with n = 6 + M parameters:
+//   every lane owns pixels: coalesced read of the packed crop (y f64 + (row,col) u16x2 = 12 B / pixel) and of the
+//   pixel's ELL row of G~ (slot-major, fixed trip count, loads issued back to back), S, exp/log, residual r and
+//   curvature weight d.
+//   DENSE classes (n <= 40): the pixel's dense Jacobian row is staged in LDS (float32, column-major, conflict
+//   free) and lanes re-map to (4x4 Hessian tile, pixel slice) for a register-tiled J^T diag(d) J in float64;
+//   slices are combined with wavefront shuffles.  Bit-reproducible.
+//   SPARSE classes (n > 40): each pixel adds its (6+z)^2/2 products straight into the packed Hessian in LDS with
+//   ds_add_f64; the crop is stored scattered (CandDesc.perm_inv) so that the 64 lanes of a wave touch different
+//   (j,k) entries.  The 6x6 polynomial block, its gradient and psi are register sums reduced with wavefront
+//   shuffles + one LDS hop.
 #include "sdsm_common.h"
 
 extern __shared__ __align__(16) unsigned char sdsm_smem[];
@@ -30,82 +34,113 @@ namespace {
 #define LS_ALPHA 0.01
 #define LS_BETA 0.5
 #define LS_MAX 40
+#define ZREG 28          // ELL slots held in registers by the sparse path (covers zcap = 25 of the default ratios)
 
 // Compile-time LDS layout (offsets in doubles from the start of dynamic LDS).
-template <int NMAX, int B, bool INPLACE>
+template <int NMAX, int B, bool INPLACE, bool DENSE>
 struct Lay {
     static constexpr int NP = NMAX * (NMAX + 1) / 2;
-    static constexpr int X = 0, G = NMAX, D = 2 * NMAX, XT = 3 * NMAX, SC = 4 * NMAX, YROW = 5 * NMAX, TMP = 6 * NMAX;
-    static constexpr int RED = 7 * NMAX + 2, FLAG = RED + 8, DW = FLAG + 2, RW = DW + B, HP = RW + B;
+    static constexpr int W = NMAX + 2;    // vectors are indexed up to n (right-hand-side row) inclusive
+    static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
+    static constexpr int RED = 7 * W, FLAG = RED + SDSM_WAVES * 32, DW = FLAG + 2;
+    static constexpr int RW = DW + (DENSE ? B : 0), HP = RW + (DENSE ? B : 0);
     static constexpr int LP = INPLACE ? HP : HP + NP;
     static constexpr int END = LP + NP;
     static constexpr int V_BYTES = ((END * 8 + 15) / 16) * 16;
     static constexpr int LDV = ((NMAX + 3) / 4) * 4;
-    static constexpr int TOTAL_BYTES = V_BYTES + LDV * B * 4;
+    static constexpr int TOTAL_BYTES = V_BYTES + (DENSE ? LDV * B * 4 : 0);
 };
 
 #define SD ((double *)sdsm_smem)
 
+#ifdef SDSM_PROFILE
+#define PROF_ARG , prof_acc
+#define PROF_PARAM , long long *prof_acc
+#else
+#define PROF_ARG
+#define PROF_PARAM
+#endif
+
 struct Cand {                       // per-candidate global pointers (already offset) and scalars
-    const double *crop_y;
-    const uint32_t *crop_rc;
-    const uint16_t *ell_idx;
-    const float *ell_w;
-    const uint16_t *ell_nnz;
-    double *hsave;
-    int N;
+    g_cdouble_p crop_y;
+    g_cu32_p crop_rc;
+    g_cu16_p ell_idx;
+    g_cfloat_p ell_w;
+    g_cu16_p ell_nnz;
+    g_double_p hsave;
+    int N, zmax;
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
 };
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
 
-struct PixelEval { double q0, q1, q2, q3, q4, phi, r, dcurv; int nnz; };
-
-// One pixel's surface value and loss terms.  xo: LDS offset (doubles) of the parameter vector (local basis).
-template <bool NEED_DERIV>
-__device__ __forceinline__ PixelEval eval_pixel(const Cand &c, int xo, int M, int p)
+// loss terms of one pixel given t = y * S     (dsm.py:298-300, 306-310, 319-322, 344, 361-366)
+__device__ __forceinline__ void loss_terms(double yv, double S, double *phi, double *r, double *dcurv)
 {
-    PixelEval e;
-    const double *xv = SD + xo;
-    double yv = c.crop_y[p];
-    uint32_t rc = c.crop_rc[p];
-    double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-    e.q0 = u * u; e.q1 = v * v; e.q2 = 2 * (u * v); e.q3 = 2 * u; e.q4 = 2 * v;
-    double S = e.q0 * xv[0] + e.q1 * xv[1] + e.q2 * xv[2] + e.q3 * xv[3] + e.q4 * xv[4] + xv[5];
-    int nnz = 0;
-    if (M > 0) {
-        nnz = c.ell_nnz[p];
-        double gx = 0;
-        for (int s = 0; s < nnz; s++) {
-            size_t o = (size_t)s * c.N + p;
-            gx += (double)c.ell_w[o] * xv[6 + c.ell_idx[o]];
-        }
-        S += gx;
-    }
-    e.nnz = nnz;
     double t = yv * S, theta;
-    if (t >= -LOG_DBL_MAX) {            // dsm.py:298-300
+    if (t >= -LOG_DBL_MAX) {
         double h = exp(-t);
-        e.phi = log(1 + h);             // dsm.py:321
-        theta = h / (1 + h);            // dsm.py:310
-    } else { e.phi = -t; theta = 1; }   // dsm.py:322,309
-    if (NEED_DERIV) {
-        e.r = -yv * theta;                              // dsm.py:344
-        e.dcurv = yv * yv * (theta - theta * theta);    // y^2 kappa, dsm.py:361-366
+        *phi = log(1 + h);
+        theta = h / (1 + h);
+    } else { *phi = -t; theta = 1; }
+    *r = -yv * theta;
+    *dcurv = yv * yv * (theta - theta * theta);
+}
+
+// G~ xi for pixel p.  Rows are padded with (index 0, weight 0) up to zmax, so the trip count is uniform; when the
+// row fits ZREG slots every load of the row is issued before the first use (memory-level parallelism: one wave
+// per SIMD has nothing else to hide the L2 latency behind).
+__device__ __forceinline__ double smooth_term(const Cand &c, const double *xv, int p)
+{
+    double gx = 0;
+    if (c.zmax <= ZREG) {
+        float w[ZREG]; int id[ZREG];
+#pragma unroll
+        for (int s = 0; s < ZREG; s++) {            // branch free: clamp the slot (uniform), select the weight
+            const int se = s < c.zmax ? s : c.zmax - 1;
+            const size_t o = (size_t)se * c.N + p;
+            const float wv = c.ell_w[o];
+            id[s] = c.ell_idx[o];
+            w[s] = s < c.zmax ? wv : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < ZREG; s++) gx += (double)w[s] * xv[6 + id[s]];
+        return gx;
     }
-    return e;
+    for (int s0 = 0; s0 < c.zmax; s0 += 4) {
+        float w[4]; int id[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int s = s0 + k < c.zmax ? s0 + k : c.zmax - 1;
+            size_t o = (size_t)s * c.N + p;
+            w[k] = s0 + k < c.zmax ? c.ell_w[o] : 0.f;
+            id[k] = c.ell_idx[o];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) gx += (double)w[k] * xv[6 + id[k]];
+    }
+    return gx;
 }
 
 // psi only (line search, final energy).  Result broadcast to all threads.
 template <class L>
 __device__ __noinline__ double eval_value(const Cand &c, int xo, int M)
 {
+    const double *xv = SD + xo;
     double psi = 0;
-    for (int p = threadIdx.x; p < c.N; p += SDSM_WG) psi += eval_pixel<false>(c, xo, M, p).phi;
+    for (int p = threadIdx.x; p < c.N; p += SDSM_WG) {
+        double yv = c.crop_y[p];
+        uint32_t rc = c.crop_rc[p];
+        double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
+        double S = u * u * xv[0] + v * v * xv[1] + 2 * (u * v) * xv[2] + 2 * u * xv[3] + 2 * v * xv[4] + xv[5];
+        if (M > 0) S += smooth_term(c, xv, p);
+        double phi, r, dc;
+        loss_terms(yv, S, &phi, &r, &dc);
+        psi += phi;
+    }
     psi = block_sum(psi, SD + L::RED);
     if (M > 0) {                                         // dsm.py:323-331
-        const double *xv = SD + xo;
         double s2 = 0;
         for (int j = threadIdx.x; j < M; j += SDSM_WG) s2 += sqrt(xv[6 + j] * xv[6 + j] + c.epsilon);
         s2 = block_sum(s2, SD + L::RED);
@@ -115,70 +150,107 @@ __device__ __noinline__ double eval_value(const Cand &c, int xo, int M)
     return psi;
 }
 
-// Full evaluation at the parameters stored at L::X: psi returned (broadcast); gradient at L::G and packed lower
-// Hessian at L::HP filled, unscaled.
-template <class L, int TPL, int B>
-__device__ __forceinline__ double eval_full(const Cand &c, int M)
+// regulariser contributions to psi, gradient and Hessian diagonal (dsm.py:323-331, 349, 372-376)
+template <class L>
+__device__ __forceinline__ double add_regulariser(const Cand &c, int M)
 {
+    const double *xv = SD + L::X;
+    double *g = SD + L::G, *Hp = SD + L::HP;
+    double s2 = 0;
+    for (int j = threadIdx.x; j < M; j += SDSM_WG) {
+        double xi = xv[6 + j], t3 = xi * xi, t2 = sqrt(t3 + c.epsilon);
+        s2 += t2;
+        g[6 + j] += c.alpha * (xi / t2);
+        double gd = c.alpha * (1 / t2 - t3 / (t2 * t2 * t2));
+        Hp[tri(6 + j, 6 + j)] += gd < 0 ? 0 : gd;
+    }
+    s2 = block_sum(s2, SD + L::RED);
+    double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
+    return o2 < 0 ? 0 : o2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DENSE full evaluation (n <= 40): Jacobian rows staged in LDS, register-tiled float64 accumulation.
+// ---------------------------------------------------------------------------------------------------------
+template <class L, int B>
+__device__ __forceinline__ double eval_full_dense(const Cand &c, int M PROF_PARAM)
+{
+    long long pt = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M, nb = (n + 3) / 4, ldv = nb * 4;
-    const int Th = nb * (nb + 1) / 2, T = Th + nb;
+    const int Th = nb * (nb + 1) / 2, T = Th + nb;      // Hessian tiles + gradient tiles (<= 65 for n <= 40)
     float *V = (float *)(sdsm_smem + L::V_BYTES);
     double *dW = SD + L::DW, *rW = SD + L::RW;
-    // lane -> (tile, slice): few tiles -> several pixel slices per tile (power of two, consecutive lanes);
-    // many tiles -> TPL tiles per lane.
-    const bool sliced = T <= SDSM_WG;
+    const double *xv = SD + L::X;
     int S = 1;
-    if (sliced) { while (S * 2 * T <= SDSM_WG && S < 64) S *= 2; }
-    const int slice = tid % S;
-    int tileJ[TPL], tileK[TPL];
-    bool tileOn[TPL];
+    while (S * 2 * T <= SDSM_WG && S < 64) S *= 2;      // pixel slices per tile: power of two, consecutive lanes
+    const int slice = tid % S, t = tid / S;
+    const bool tileOn = t < T;
+    int J = 0, K = 0;
+    if (t < Th) {
+        J = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (J * (J + 1) / 2 > t) J--;
+        while ((J + 1) * (J + 2) / 2 <= t) J++;
+        K = t - J * (J + 1) / 2;
+    } else if (tileOn) { J = t - Th; K = -1; }          // gradient tile
+    double acc[16];
 #pragma unroll
-    for (int q = 0; q < TPL; q++) {
-        int t = sliced ? (q == 0 ? tid / S : T) : tid + q * SDSM_WG;
-        tileOn[q] = t < T;
-        if (t < Th) {
-            int J = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-            while (J * (J + 1) / 2 > t) J--;
-            while ((J + 1) * (J + 2) / 2 <= t) J++;
-            tileJ[q] = J; tileK[q] = t - J * (J + 1) / 2;
-        } else { tileJ[q] = t - Th; tileK[q] = -1; }       // gradient tile
-        if (!tileOn[q]) { tileJ[q] = 0; tileK[q] = 0; }
-    }
-    double acc[TPL][16];
-#pragma unroll
-    for (int q = 0; q < TPL; q++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[q][e] = 0;
-
-    double psi = 0, gq0 = 0, gq1 = 0, gq2 = 0, gq3 = 0, gq4 = 0, gq5 = 0;
+    for (int e = 0; e < 16; e++) acc[e] = 0;
+    double red[7] = {0, 0, 0, 0, 0, 0, 0};              // psi, g_theta[0..5]
     for (int base = 0; base < c.N; base += B) {
-        // ---- phase A: lane = pixel ---------------------------------------------------------------
+        // ---- stage: lane = pixel ---------------------------------------------------------------
         for (int lp = tid; lp < B; lp += SDSM_WG) {
             int p = base + lp;
             if (p < c.N) {
-                PixelEval e = eval_pixel<true>(c, L::X, M, p);
-                psi += e.phi;
-                gq0 += e.r * e.q0; gq1 += e.r * e.q1; gq2 += e.r * e.q2; gq3 += e.r * e.q3; gq4 += e.r * e.q4; gq5 += e.r;
-                V[0 * B + lp] = (float)e.q0; V[1 * B + lp] = (float)e.q1; V[2 * B + lp] = (float)e.q2;
-                V[3 * B + lp] = (float)e.q3; V[4 * B + lp] = (float)e.q4; V[5 * B + lp] = 1.f;
+                double yv = c.crop_y[p];
+                uint32_t rc = c.crop_rc[p];
+                double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
+                double q0 = u * u, q1 = v * v, q2 = 2 * (u * v), q3 = 2 * u, q4 = 2 * v;
+                double Sv = q0 * xv[0] + q1 * xv[1] + q2 * xv[2] + q3 * xv[3] + q4 * xv[4] + xv[5];
+                V[0 * B + lp] = (float)q0; V[1 * B + lp] = (float)q1; V[2 * B + lp] = (float)q2;
+                V[3 * B + lp] = (float)q3; V[4 * B + lp] = (float)q4; V[5 * B + lp] = 1.f;
                 for (int col = 6; col < ldv; col++) V[col * B + lp] = 0.f;
-                for (int s = 0; s < e.nnz; s++) {
-                    size_t o = (size_t)s * c.N + p;
-                    V[(6 + c.ell_idx[o]) * B + lp] = c.ell_w[o];
+                if (M > 0) {
+                    double gx = 0;
+                    if (c.zmax <= ZREG) {
+                        float w[ZREG]; int id[ZREG];
+#pragma unroll
+                        for (int s = 0; s < ZREG; s++) {
+                            const int se = s < c.zmax ? s : c.zmax - 1;
+                            const size_t o = (size_t)se * c.N + p;
+                            const float wv = c.ell_w[o];
+                            id[s] = c.ell_idx[o];
+                            w[s] = s < c.zmax ? wv : 0.f;
+                        }
+#pragma unroll
+                        for (int s = 0; s < ZREG; s++) {
+                            gx += (double)w[s] * xv[6 + id[s]];
+                            if (w[s] != 0.f) V[(6 + id[s]) * B + lp] = w[s];
+                        }
+                    } else {
+                        for (int s = 0; s < c.zmax; s++) {
+                            size_t o = (size_t)s * c.N + p;
+                            float w = c.ell_w[o]; int id = c.ell_idx[o];
+                            gx += (double)w * xv[6 + id];
+                            if (w != 0.f) V[(6 + id) * B + lp] = w;
+                        }
+                    }
+                    Sv += gx;
                 }
-                dW[lp] = e.dcurv; rW[lp] = e.r;
+                double phi, r, dc;
+                loss_terms(yv, Sv, &phi, &r, &dc);
+                red[0] += phi;
+                red[1] += r * q0; red[2] += r * q1; red[3] += r * q2; red[4] += r * q3; red[5] += r * q4; red[6] += r;
+                dW[lp] = dc; rW[lp] = r;
             } else {
                 for (int col = 0; col < ldv; col++) V[col * B + lp] = 0.f;
                 dW[lp] = 0; rW[lp] = 0;
             }
         }
         __syncthreads();
-        // ---- phase B: lane = (tile, slice); quads of 4 staged pixels ----------------------------
-#pragma unroll
-        for (int q = 0; q < TPL; q++) {
-            if (!tileOn[q]) continue;
-            const int J = tileJ[q], K = tileK[q];
+        PROF_ADD(0, pt);
+        // ---- accumulate: lane = (tile, slice); quads of 4 staged pixels --------------------------
+        if (tileOn) {
             for (int quad = slice; quad < B / 4; quad += S) {
                 const int p4 = quad * 4;
                 const float4 a0 = *(const float4 *)&V[(4 * J + 0) * B + p4];
@@ -197,79 +269,161 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M)
                         const double ax = (double)av[i].x * w01.x, ay = (double)av[i].y * w01.y, az = (double)av[i].z * w23.x, aw = (double)av[i].w * w23.y;
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            acc[q][i * 4 + j] += ax * (double)bv[j].x + ay * (double)bv[j].y + az * (double)bv[j].z + aw * (double)bv[j].w;
+                            acc[i * 4 + j] += ax * (double)bv[j].x + ay * (double)bv[j].y + az * (double)bv[j].z + aw * (double)bv[j].w;
                     }
                 } else {
                     const double2 r01 = *(const double2 *)&rW[p4], r23 = *(const double2 *)&rW[p4 + 2];
-                    acc[q][0] += (double)a0.x * r01.x + (double)a0.y * r01.y + (double)a0.z * r23.x + (double)a0.w * r23.y;
-                    acc[q][1] += (double)a1.x * r01.x + (double)a1.y * r01.y + (double)a1.z * r23.x + (double)a1.w * r23.y;
-                    acc[q][2] += (double)a2.x * r01.x + (double)a2.y * r01.y + (double)a2.z * r23.x + (double)a2.w * r23.y;
-                    acc[q][3] += (double)a3.x * r01.x + (double)a3.y * r01.y + (double)a3.z * r23.x + (double)a3.w * r23.y;
+                    acc[0] += (double)a0.x * r01.x + (double)a0.y * r01.y + (double)a0.z * r23.x + (double)a0.w * r23.y;
+                    acc[1] += (double)a1.x * r01.x + (double)a1.y * r01.y + (double)a1.z * r23.x + (double)a1.w * r23.y;
+                    acc[2] += (double)a2.x * r01.x + (double)a2.y * r01.y + (double)a2.z * r23.x + (double)a2.w * r23.y;
+                    acc[3] += (double)a3.x * r01.x + (double)a3.y * r01.y + (double)a3.z * r23.x + (double)a3.w * r23.y;
                 }
             }
         }
         __syncthreads();
+        PROF_ADD(1, pt);
     }
     // ---- combine slices (consecutive lanes of one wave), scatter into the packed Hessian / gradient ----
     double *Hp = SD + L::HP, *g = SD + L::G;
 #pragma unroll
-    for (int q = 0; q < TPL; q++) {
-        if (sliced && q > 0) break;
+    for (int e = 0; e < 16; e++) {
+        double v = acc[e];
+        for (int o = 1; o < S; o <<= 1) v += __shfl_xor(v, o);
+        acc[e] = v;
+    }
+    if (tileOn && slice == 0) {
+        if (K >= 0) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            double v = acc[q][e];
-            for (int o = 1; o < S; o <<= 1) v += __shfl_xor(v, o);
-            acc[q][e] = v;
-        }
-        if (tileOn[q] && slice == 0) {
-            const int J = tileJ[q], K = tileK[q];
-            if (K >= 0) {
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) {
+                    int row = 4 * J + i, col = 4 * K + j;
+                    if (row < n && col <= row) Hp[tri(row, col)] = acc[i * 4 + j];
+                }
+        } else {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        int row = 4 * J + i, col = 4 * K + j;
-                        if (row < n && col <= row) Hp[tri(row, col)] = acc[q][i * 4 + j];
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) { int row = 4 * J + i; if (row >= 6 && row < n) g[row] = acc[q][i]; }
-            }
+            for (int i = 0; i < 4; i++) { int row = 4 * J + i; if (row >= 6 && row < n) g[row] = acc[i]; }
         }
     }
-    double *red = SD + L::RED;
-    psi = block_sum(psi, red);
-    gq0 = block_sum(gq0, red); gq1 = block_sum(gq1, red); gq2 = block_sum(gq2, red);
-    gq3 = block_sum(gq3, red); gq4 = block_sum(gq4, red); gq5 = block_sum(gq5, red);
-    if (tid == 0) { g[0] = gq0; g[1] = gq1; g[2] = gq2; g[3] = gq3; g[4] = gq4; g[5] = gq5; }
+    block_sum_vec<7>(red, SD + L::RED);
+    if (tid < 6) g[tid] = red[1 + tid];
     __syncthreads();
-    if (M > 0) {                                          // regulariser, dsm.py:323-331, 349, 372-376
-        const double *xv = SD + L::X;
-        double s2 = 0;
-        for (int j = tid; j < M; j += SDSM_WG) {
-            double xi = xv[6 + j], t3 = xi * xi, t2 = sqrt(t3 + c.epsilon);
-            s2 += t2;
-            g[6 + j] += c.alpha * (xi / t2);
-            double gd = c.alpha * (1 / t2 - t3 / (t2 * t2 * t2));
-            Hp[tri(6 + j, 6 + j)] += gd < 0 ? 0 : gd;
-        }
-        s2 = block_sum(s2, red);
-        double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
-        psi += o2 < 0 ? 0 : o2;
-    }
+    double psi = red[0];
+    if (M > 0) psi += add_regulariser<L>(c, M);
     __syncthreads();
+    PROF_ADD(2, pt);
     return psi;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// SPARSE full evaluation (n > 40): per-pixel products added into the packed Hessian in LDS (ds_add_f64).
+// ---------------------------------------------------------------------------------------------------------
+template <class L>
+__device__ __forceinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
+{
+    long long pt = PROF_NOW();
+    const int tid = threadIdx.x;
+    const int n = 6 + M, np = n * (n + 1) / 2;
+    double *Hp = SD + L::HP, *g = SD + L::G;
+    const double *xv = SD + L::X;
+    for (int e = tid; e < np; e += SDSM_WG) Hp[e] = 0;
+    for (int i = tid; i < n; i += SDSM_WG) g[i] = 0;
+    __syncthreads();
+    double red[28];                                      // psi, g_theta[6], 6x6 lower triangle (21)
+#pragma unroll
+    for (int k = 0; k < 28; k++) red[k] = 0;
+    const int zm = M > 0 ? c.zmax : 0;
+    const bool in_regs = zm <= ZREG;
+    for (int p = tid; p < c.N; p += SDSM_WG) {
+        double yv = c.crop_y[p];
+        uint32_t rc = c.crop_rc[p];
+        double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
+        double q[6] = {u * u, v * v, 2 * (u * v), 2 * u, 2 * v, 1.0};
+        double Sv = q[0] * xv[0] + q[1] * xv[1] + q[2] * xv[2] + q[3] * xv[3] + q[4] * xv[4] + xv[5];
+        const int nnz = M > 0 ? (int)c.ell_nnz[p] : 0;
+        float w[ZREG]; int id[ZREG];
+        if (in_regs) {
+#pragma unroll
+            for (int s = 0; s < ZREG; s++) {
+                const int se = s < zm ? s : (zm > 0 ? zm - 1 : 0);
+                const size_t o = (size_t)se * c.N + p;
+                const float wv = zm > 0 ? c.ell_w[o] : 0.f;
+                id[s] = zm > 0 ? (int)c.ell_idx[o] : 0;
+                w[s] = s < zm ? wv : 0.f;
+            }
+            double gx = 0;
+#pragma unroll
+            for (int s = 0; s < ZREG; s++) gx += (double)w[s] * xv[6 + id[s]];
+            Sv += gx;
+        } else if (M > 0) Sv += smooth_term(c, xv, p);
+        double phi, r, dc;
+        loss_terms(yv, Sv, &phi, &r, &dc);
+        red[0] += phi;
+#pragma unroll
+        for (int a = 0; a < 6; a++) red[1 + a] += r * q[a];
+        {
+            int e = 7;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++) red[e++] += dc * q[a] * q[b];
+        }
+        if (dc != 0 || r != 0) {
+            if (in_regs) {
+#pragma unroll
+                for (int a = 0; a < ZREG; a++) {
+                    if (a < nnz) {
+                        const double wa = (double)w[a], dwa = dc * wa;
+                        const int ra = 6 + id[a];
+                        double *Hrow = Hp + tri(ra, 0);
+                        atomicAdd(&g[ra], r * wa);
+#pragma unroll
+                        for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
+#pragma unroll
+                        for (int b = 0; b <= a; b++) atomicAdd(&Hrow[6 + id[b]], dwa * (double)w[b]);   // id ascending within a row
+                    }
+                }
+            } else {
+                for (int a = 0; a < nnz; a++) {
+                    size_t oa = (size_t)a * c.N + p;
+                    const double wa = (double)c.ell_w[oa], dwa = dc * wa;
+                    const int ra = 6 + c.ell_idx[oa];
+                    double *Hrow = Hp + tri(ra, 0);
+                    atomicAdd(&g[ra], r * wa);
+                    for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
+                    for (int b = 0; b <= a; b++) { size_t ob = (size_t)b * c.N + p; atomicAdd(&Hrow[6 + c.ell_idx[ob]], dwa * (double)c.ell_w[ob]); }
+                }
+            }
+        }
+    }
+    PROF_ADD(0, pt);
+    block_sum_vec<28>(red, SD + L::RED);
+    if (tid < 6) g[tid] = red[1 + tid];
+    if (tid < 21) {
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= tid) a++;
+        Hp[tri(a, tid - a * (a + 1) / 2)] = red[7 + tid];
+    }
+    __syncthreads();
+    double psi = red[0];
+    if (M > 0) psi += add_regulariser<L>(c, M);
+    __syncthreads();
+    PROF_ADD(2, pt);
+    return psi;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Solve H d = -g with Jacobi scaling and an escalating diagonal shift (same schedule as the oracle).
-// Returns false on numerical failure.  *lam2 = -g.d (unscaled).  INPLACE: the factor overwrites the Hessian;
-// a copy is kept in global memory (c.hsave) so that a failed factorisation can be retried.
+// Right-looking Cholesky of the scaled matrix, the right-hand side rides along as row n; all 256 threads update
+// the trailing sub-matrix of every column.  Returns false on numerical failure.  *lam2 = -g.d (unscaled).
+// INPLACE: the factor overwrites the Hessian; a copy is kept in global memory (c.hsave) for retries.
+// ---------------------------------------------------------------------------------------------------------
 template <class L, bool INPLACE>
 __device__ __forceinline__ bool factor_solve(const Cand &c, int n, double *lam2)
 {
     const int tid = threadIdx.x;
     const int np = n * (n + 1) / 2;
-    double *Hp = SD + L::HP, *Lp = SD + L::LP, *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *tmp = SD + L::TMP, *d = SD + L::D;
+    double *Hp = SD + L::HP, *Lp = SD + L::LP, *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *colj = SD + L::XT;   // XT is free between line searches
     int *flag = (int *)(SD + L::FLAG);
     bool finite = true;
     for (int i = tid; i < n; i += SDSM_WG) {
@@ -289,48 +443,52 @@ __device__ __forceinline__ bool factor_solve(const Cand &c, int n, double *lam2)
     __syncthreads();
     if (*flag) return false;
 
+    const int ri = tid >> 4, ki = tid & 15;                   // 16 x 16 thread grid over the trailing sub-matrix
     double tau = 0;
     bool ok = false;
     for (int attempt = 0; attempt < 12 && !ok; attempt++) {
-        for (int e = tid; e < np; e += SDSM_WG) {
-            int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while (i * (i + 1) / 2 > e) i--;
-            while ((i + 1) * (i + 2) / 2 <= e) i++;
-            int j = e - i * (i + 1) / 2;
-            double v = (INPLACE ? c.hsave[e] : Hp[e]) * sc[i] * sc[j];
-            if (i == j) v += tau;
-            Lp[e] = v;
+        // scaled copy: thread grid over (row, column)
+        for (int i = ri; i < n; i += 16) {
+            const double si = sc[i];
+            for (int k = ki; k <= i; k += 16) {
+                double v = (INPLACE ? c.hsave[tri(i, k)] : Hp[tri(i, k)]) * si * sc[k];
+                if (i == k) v += tau;
+                Lp[tri(i, k)] = v;
+            }
         }
+        for (int k = tid; k < n; k += SDSM_WG) yrow[k] = -g[k] * sc[k];
         __syncthreads();
         ok = true;
         for (int j = 0; j < n; j++) {
-            for (int i = j + tid; i <= n; i += SDSM_WG) {     // row n = right-hand side -g * sc
-                double s;
-                const double *Lj = Lp + tri(j, 0);
-                if (i < n) {
-                    const double *Li = Lp + tri(i, 0);
-                    s = Li[j];
-                    for (int k = 0; k < j; k++) s -= Li[k] * Lj[k];
-                } else {
-                    s = -g[j] * sc[j];
-                    for (int k = 0; k < j; k++) s -= yrow[k] * Lj[k];
-                }
-                tmp[i] = s;
+            const double piv = Lp[tri(j, j)];                  // final: all trailing updates of column j - 1 are done
+            if (!(piv > 1e-300) || !isfinite(piv)) { ok = false; break; }
+            const double ljj = sqrt(piv), rl = 1.0 / ljj;
+            if (tid == 0) dg[j] = ljj;                         // the diagonal of L lives in dg[]; Lp keeps the pivot
+            for (int i = j + 1 + tid; i <= n; i += SDSM_WG) {  // scale column j (row n = right-hand side)
+                double v = (i < n ? Lp[tri(i, j)] : yrow[j]) * rl;
+                if (i < n) Lp[tri(i, j)] = v; else yrow[j] = v;
+                colj[i] = v;                                   // contiguous copy of the column for the update below
             }
             __syncthreads();
-            double piv = tmp[j];
-            if (!(piv > 1e-300) || !isfinite(piv)) ok = false;
-            if (ok) {
-                double ljj = sqrt(piv);
-                for (int i = j + tid; i <= n; i += SDSM_WG) {
-                    if (i == j) Lp[tri(j, j)] = ljj;
-                    else if (i < n) Lp[tri(i, j)] = tmp[i] / ljj;
-                    else yrow[j] = tmp[n] / ljj;
+            for (int i = j + 1 + ri; i <= n; i += 16) {        // trailing update, 4 independent entries in flight
+                const double lij = colj[i];
+                double *Li = i < n ? Lp + tri(i, 0) : yrow;
+                const int kend = i < n ? i : n - 1;
+                for (int k = j + 1 + ki; k <= kend; k += 64) {
+                    const int k1 = k + 16, k2 = k + 32, k3 = k + 48;
+                    const double a0 = Li[k], c0 = colj[k];
+                    const double a1 = k1 <= kend ? Li[k1] : 0, c1 = k1 <= kend ? colj[k1] : 0;
+                    const double a2 = k2 <= kend ? Li[k2] : 0, c2 = k2 <= kend ? colj[k2] : 0;
+                    const double a3 = k3 <= kend ? Li[k3] : 0, c3 = k3 <= kend ? colj[k3] : 0;
+                    Li[k] = a0 - lij * c0;
+                    if (k1 <= kend) Li[k1] = a1 - lij * c1;
+                    if (k2 <= kend) Li[k2] = a2 - lij * c2;
+                    if (k3 <= kend) Li[k3] = a3 - lij * c3;
                 }
             }
             __syncthreads();
-            if (!ok) break;
         }
+        __syncthreads();
         if (!ok) tau = tau == 0 ? 1e-12 : tau * 100;
     }
     if (!ok) return false;
@@ -338,9 +496,8 @@ __device__ __forceinline__ bool factor_solve(const Cand &c, int n, double *lam2)
     for (int i = tid; i < n; i += SDSM_WG) l2 += yrow[i] * yrow[i];
     l2 = block_sum(l2, SD + L::RED);
     for (int k = n - 1; k >= 0; k--) {                        // back substitution L^T z = yrow
-        if (tid == 0) d[k] = yrow[k] / Lp[tri(k, k)];
-        __syncthreads();
-        double dk = d[k];
+        const double dk = yrow[k] / dg[k];
+        if (tid == 0) d[k] = dk;
         const double *Lk = Lp + tri(k, 0);
         for (int i = tid; i < k; i += SDSM_WG) yrow[i] -= Lk[i] * dk;
         __syncthreads();
@@ -356,16 +513,19 @@ __device__ __forceinline__ bool factor_solve(const Cand &c, int n, double *lam2)
 
 // Damped Newton on f = scale * psi from the parameters at L::X (in/out).
 // Returns 0 optimal, 1 unknown (iteration cap / stalled line search), 2 numerical failure.
-template <class L, int TPL, int B, bool INPLACE>
-__device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, double *psi_out, int *iters_out, int *ev_value, int *ev_full)
+template <class L, int B, bool INPLACE, bool DENSE>
+__device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, double *psi_out, int *iters_out, int *ev_value, int *ev_full PROF_PARAM)
 {
     const int tid = threadIdx.x, n = 6 + M;
     double *x = SD + L::X, *xt = SD + L::XT, *d = SD + L::D;
     double tprev = 1;
     int status = 1, iters = 0;
     for (;;) {
-        double psi = eval_full<L, TPL, B>(c, M);
+        double psi;
+        if (DENSE) psi = eval_full_dense<L, B>(c, M PROF_ARG);
+        else psi = eval_full_sparse<L>(c, M PROF_ARG);
         (*ev_full)++;
+        long long pt = PROF_NOW();
         double f = c.scale * psi;
         if (iters >= max_iters) { status = 1; break; }
         if (!isfinite(f)) { status = 2; break; }
@@ -373,6 +533,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         if (!factor_solve<L, INPLACE>(c, n, &lam2u)) { status = 2; break; }
         double lam2 = c.scale * lam2u;
         iters++;
+        PROF_ADD(3, pt);
         if (lam2 * 0.5 <= NEWTON_ABSTOL + NEWTON_RELTOL * fabs(f)) {
             for (int i = tid; i < n; i += SDSM_WG) x[i] += d[i];          // final full step
             __syncthreads();
@@ -389,6 +550,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
             if (isfinite(ft) && ft <= f - LS_ALPHA * t * lam2) { accepted = true; break; }
             t *= LS_BETA;
         }
+        PROF_ADD(4, pt);
         if (!accepted) { status = 1; break; }
         tprev = t;
         for (int i = tid; i < n; i += SDSM_WG) x[i] = xt[i];
@@ -417,11 +579,11 @@ __device__ __forceinline__ void reparam(const double *th, double p0, double p1, 
 // NMAX: largest 6 + M this instantiation handles; candidates with 6 + M in (nmin_excl, NMAX] are processed,
 // the others are left to the other classes.  The smallest class also writes the records of trivial /
 // failed-setup candidates.
-template <int NMAX, int TPL, int B, bool INPLACE, int WPE>
+template <int NMAX, int B, bool INPLACE, bool DENSE, int WPE>
 __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int nmin_excl, int handles_rest, sdsm_record *records,
-                                                         uint32_t *masks, double *xi_out)
+                                                              uint32_t *masks, double *xi_out)
 {
-    using L = Lay<NMAX, B, INPLACE>;
+    using L = Lay<NMAX, B, INPLACE, DENSE>;
     const int tid = threadIdx.x;
     const int ci = P.order[blockIdx.x];
     const CandDesc cd = P.cand[ci];
@@ -444,10 +606,10 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
     if (!(nfull > nmin_excl && nfull <= NMAX)) return;
 
     Cand c;
-    c.N = cd.N;
-    c.crop_y = P.crop_y + cd.crop_off; c.crop_rc = P.crop_rc + cd.crop_off; c.ell_nnz = P.ell_nnz + cd.crop_off;
-    c.ell_idx = P.ell_idx + cd.ell_off; c.ell_w = P.ell_w + cd.ell_off;
-    c.hsave = (INPLACE && cd.hsave_slot >= 0) ? P.hsave + (int64_t)cd.hsave_slot * P.hsave_stride : nullptr;
+    c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0;
+    c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_nnz = (g_cu16_p)(P.ell_nnz + cd.crop_off);
+    c.ell_idx = (g_cu16_p)(P.ell_idx + cd.ell_off); c.ell_w = (g_cfloat_p)(P.ell_w + cd.ell_off);
+    c.hsave = (g_double_p)((INPLACE && cd.hsave_slot >= 0) ? P.hsave + (int64_t)cd.hsave_slot * P.hsave_stride : nullptr);
     c.scale = P.scale / cd.N;                                   // objects.py:380
     c.epsilon = P.epsilon; c.alpha = P.alpha;
     // local frame: centre of the bounding box, half extents
@@ -459,6 +621,10 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
     const double P0 = 1.0 / (c.inv_hr * z0), P1 = 1.0 / (c.inv_hc * z1), O0 = c.rmid / z0, O1 = c.cmid / z1;
     double *x = SD + L::X, *xt = SD + L::XT;
 
+#ifdef SDSM_PROFILE
+    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long prof_t_start = PROF_NOW();
+#endif
     sdsm_record r = {};
     r.n_pixels = cd.N; r.n_deform = st.M;
     int status_final = SDSM_CAND_OPTIMAL;
@@ -506,7 +672,10 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
             __syncthreads();
         }
         double psi; int its;
-        int s = newton<L, TPL, B, INPLACE>(c, M, P.max_iters, &psi, &its, &ev_value, &ev_full);
+        int s = newton<L, B, INPLACE, DENSE>(c, M, P.max_iters, &psi, &its, &ev_value, &ev_full PROF_ARG);
+#ifdef SDSM_PROFILE
+        if (phase < 2) { prof_acc[6] = PROF_NOW() - prof_t_start; }
+#endif
         if (phase < 2) {
             r.iters_ell += its;
             if (s != 2) { have = true; psi_ell = psi; for (int i = 0; i < 6; i++) keep[i] = x[i]; s_prev = s; }
@@ -550,12 +719,7 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
             int pr = rc >> 16, pc = rc & 0xffffu;
             double u = ((double)pr - c.rmid) * c.inv_hr, v = ((double)pc - c.cmid) * c.inv_hc;
             double Sv = u * u * x[0] + v * v * x[1] + 2 * (u * v) * x[2] + 2 * u * x[3] + 2 * v * x[4] + x[5];
-            if (Mfull > 0) {
-                int nnz = c.ell_nnz[p];
-                double gx = 0;
-                for (int s = 0; s < nnz; s++) { size_t o = (size_t)s * c.N + p; gx += (double)c.ell_w[o] * x[6 + c.ell_idx[o]]; }
-                Sv += gx;
-            }
+            if (Mfull > 0) Sv += smooth_term(c, x, p);
             if (Sv > 0) {
                 int bit = (pr - cd.r0) * cd.w + (pc - cd.c0);
                 atomicOr(&mk[bit >> 5], 1u << (bit & 31));
@@ -591,31 +755,46 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
         r.status = status_final;
         r.evals_value = ev_value; r.evals_full = ev_full;
         r.on_boundary = onb;
+#ifdef SDSM_PROFILE
+        prof_acc[5] = PROF_NOW() - prof_t_start;
+        if (P.prof) for (int i = 0; i < 8; i++) P.prof[(size_t)ci * 8 + i] = prof_acc[i];
+#endif
         if (rmax >= 0) { r.fg_r0 = rmin; r.fg_c0 = cmin; r.fg_h = rmax - rmin + 1; r.fg_w = cmax - cmin + 1; }
         *rec = r;
     }
 }
 
 // ---- launch helper (called from sdsm_api.hip) ----------------------------------------------------
-// class A: n <= 40  (B 256, separate factor)           LDS ~ 60 KB
-// class B: n <= 84  (B 128, separate factor)           LDS ~ 107 KB
-// class C: n <= 172 (4 tiles per lane, B 32, in place) LDS ~ 151 KB
-template <int NMAX, int TPL, int B, bool INPLACE, int WPE>
+// class A: n <= 40   dense tiles, B 256, separate factor      LDS ~ 61 KB   (2 workgroups / CU)
+// class B: n <= 84   sparse LDS atomics, separate factor      LDS ~ 63 KB   (2 workgroups / CU)
+// class C: n <= 172  sparse LDS atomics, in-place factor      LDS ~ 130 KB  (1 workgroup / CU)
+// The three classes are independent: they run concurrently on three streams forked from the caller's stream.
+template <int NMAX, int B, bool INPLACE, bool DENSE, int WPE>
 static hipError_t launch_class(const BatchParams &P, int nmin_excl, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
-    auto kern = sdsm_k_solve<NMAX, TPL, B, INPLACE, WPE>;
-    constexpr int lds = Lay<NMAX, B, INPLACE>::TOTAL_BYTES;
-    static_assert(lds <= 160 * 1024 - 256, "LDS budget");
+    auto kern = sdsm_k_solve<NMAX, B, INPLACE, DENSE, WPE>;
+    constexpr int lds = Lay<NMAX, B, INPLACE, DENSE>::TOTAL_BYTES;
+    static_assert(lds <= 160 * 1024 - 512, "LDS budget");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(P.n), dim3(SDSM_WG), lds, stream, P, nmin_excl, handles_rest, records, masks, xi_out);
     return hipGetLastError();
 }
 
-extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
+extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
+                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipEvent_t *ev /* 3 */)
 {
     hipError_t e;
-    if ((e = launch_class<172, 4, 32, true, 1>(P, 84, 0, records, masks, xi_out, stream)) != hipSuccess) return e;
-    if ((e = launch_class<84, 1, 128, false, 1>(P, 40, 0, records, masks, xi_out, stream)) != hipSuccess) return e;
-    return launch_class<40, 1, 256, false, 2>(P, 0, 1, records, masks, xi_out, stream);
+    // fork: the side streams wait for everything queued on the caller's stream so far (setup kernel)
+    if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
+    if ((e = launch_class<172, 32, true, false, 1>(P, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+    if ((e = launch_class<84, 32, false, false, 1>(P, 40, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
+    if ((e = launch_class<40, 256, false, true, 2>(P, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
+    // join
+    if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
+    if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
+    return hipStreamWaitEvent(stream, ev[2], 0);
 }

@@ -104,8 +104,8 @@ class Batch:
 
     def __del__(self):
         plan = getattr(self, 'plan', None)
-        if plan:
-            _capi.lib().sdsm_plan_destroy(plan)
+        if plan and _capi is not None and _capi._lib is not None:
+            _capi._lib.sdsm_plan_destroy(plan)
             self.plan = None
 
     def launch(self):
@@ -152,10 +152,12 @@ class Batch:
             nnz = ell_nnz[po:po + N].astype(np.int64)
             idx = ell_idx[eo:eo + N * zcap].reshape(zcap, N) if N else np.zeros((zcap, 0), np.uint16)
             w = ell_w[eo:eo + N * zcap].reshape(zcap, N) if N else np.zeros((zcap, 0), np.float32)
-            out.append(dict(N=N, M=M, status=status, hc=hc, wc=wc, npos=npos, y=crop_y[po:po + N].copy(),
-                            r=(rc >> 16).astype(np.int64), c=(rc & 0xffff).astype(np.int64),
-                            cr=(cc >> 16).astype(np.int64), cc=(cc & 0xffff).astype(np.int64),
-                            grid_r=(g >> 16).astype(np.int64), grid_c=(g & 0xffff).astype(np.int64), nnz=nnz, idx=idx.copy(), w=w.copy()))
+            # the crop is stored in a scattered order (CandDesc.perm_inv); report it in raster order
+            o = np.lexsort(((rc & 0xffff), (rc >> 16)))
+            out.append(dict(N=N, M=M, status=status, hc=hc, wc=wc, npos=npos, zmax=int(state[i, 5]), y=crop_y[po:po + N][o].copy(),
+                            r=(rc >> 16).astype(np.int64)[o], c=(rc & 0xffff).astype(np.int64)[o],
+                            cr=(cc >> 16).astype(np.int64)[o], cc=(cc & 0xffff).astype(np.int64)[o],
+                            grid_r=(g >> 16).astype(np.int64), grid_c=(g & 0xffff).astype(np.int64), nnz=nnz[o], idx=idx[:, o].copy(), w=w[:, o].copy()))
             po += N
         return out
 

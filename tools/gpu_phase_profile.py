@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-candidate cycle counters of the solve kernel's phases (needs the -DSDSM_PROFILE build:
+SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so python tools/gpu_phase_profile.py [workload])."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from superdsm_amd import _capi, engine, testing
+
+wl = sys.argv[1] if len(sys.argv) > 1 else 'bbbc039_like'
+scene = testing.make_scene(wl, max_size=3)
+fps = scene['footprints']
+img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
+batch = engine.Batch(img, fps, scene['dsm_cfg'])
+prof = torch.zeros(len(fps) * 8, dtype=torch.int64, device='cuda')
+_capi.lib().sdsm_set_debug_buffer(C.c_void_p(prof.data_ptr()))
+for _ in range(2):
+    batch.launch()
+torch.cuda.synchronize()
+recs = batch.records()
+p = prof.cpu().numpy().reshape(-1, 8).astype(np.float64)
+names = ['phaseA', 'phaseB', 'reduce', 'factor', 'linesrch', 'total', 'ell_tot']
+n = recs['n_deform'] + 6
+cls = np.where(n <= 40, 'A', np.where(n <= 84, 'B', 'C'))
+print('cycles are shader-clock ticks of thread 0; ms = ticks / 2.4e6 (approx)')
+for c in 'ABC':
+    m = cls == c
+    if not m.any():
+        continue
+    print(f'class {c}: {m.sum()} candidates, N median {np.median(recs["n_pixels"][m]):.0f} max {recs["n_pixels"][m].max()}, M median {np.median(recs["n_deform"][m]):.0f} max {recs["n_deform"][m].max()}, '
+          f'iters_dsm median {np.median(recs["iters_dsm"][m]):.0f} max {recs["iters_dsm"][m].max()}, full evals median {np.median(recs["evals_full"][m]):.0f}, value evals median {np.median(recs["evals_value"][m]):.0f}')
+    tot = p[m, 5]
+    print('   total ms: median %.3f  max %.3f  sum %.1f' % (np.median(tot) / 2.4e6, tot.max() / 2.4e6, tot.sum() / 2.4e6))
+    for i, nm in enumerate(names[:5]):
+        print('   %-9s share of total: %.1f%%   per full eval (median): %.1f us' % (nm, 100 * p[m, i].sum() / tot.sum(), np.median(p[m, i] / np.maximum(recs['evals_full'][m], 1)) / 2400))
+    print('   elliptical share: %.1f%%' % (100 * p[m, 6].sum() / tot.sum()))
+worst = np.argsort(-p[:, 5])[:8]
+print('slowest candidates:')
+for k in worst:
+    print('  cand %d N=%d M=%d it_ell=%d it_dsm=%d evals=%d/%d total=%.2f ms  A=%.2f B=%.2f red=%.2f fac=%.2f ls=%.2f' % (
+        k, recs['n_pixels'][k], recs['n_deform'][k], recs['iters_ell'][k], recs['iters_dsm'][k], recs['evals_full'][k], recs['evals_value'][k],
+        p[k, 5] / 2.4e6, *(p[k, :5] / 2.4e6)))
