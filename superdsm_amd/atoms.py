@@ -24,9 +24,14 @@ class AtomAdjacencyGraph:
         order = idx[::-1]
         first[flat_atoms[order]] = order                # the last write wins -> smallest raster index
         self._cluster_by_atom = {int(a): int(flat_clusters[first[a]]) for a in range(1, n + 1) if present[a]}
+        # Built with in-place unions in ascending label order, as the reference does (atoms.py:63-71): CPython lays a set
+        # out differently for `|=` and `.add`, and the iteration order of these sets decides the floating-point
+        # summation order of exact ties in the pruning bound (globalenergymin.py:341-346).
         self._atoms_by_cluster = {}
         for a, cl in self._cluster_by_atom.items():
-            self._atoms_by_cluster.setdefault(cl, set()).add(a)
+            if cl not in self._atoms_by_cluster:
+                self._atoms_by_cluster[cl] = set()
+            self._atoms_by_cluster[cl] |= {a}
         self._adjacencies = {a: set() for a in range(1, n + 1)}
         cl_of = np.zeros(n + 1, np.int64)
         for a, cl in self._cluster_by_atom.items():

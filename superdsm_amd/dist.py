@@ -54,3 +54,87 @@ class RecordGather:
             nr, nm = (int(v) for v in self.sizes[r])
             out.append((buf[:nr].copy(), buf[nr:nr + nm].copy()))
         return out
+
+
+def _gpu_solve_local(image, footprints, cfg):
+    """Default local solver of a shard: one engine batch on this rank's GPU.  Returns (records bytes, mask_info
+    int32 [n,4], mask_offset int64 [n], masks bytes), all numpy."""
+    from . import engine
+    batch = engine.Batch(image, footprints, cfg)
+    batch.launch()
+    torch.cuda.synchronize(image.device)
+    n = len(footprints)
+    return (batch.records_dev.cpu().numpy()[:n * 128].copy(), batch.mask_info[:n].copy(), batch.mask_offset[:n].copy(),
+            batch.masks_dev.cpu().numpy().copy())
+
+
+def fragments_from_masks(records, mask_info, mask_offset, masks):
+    """Foreground fragments from bit-packed region-bbox masks (same rule as engine.Batch.fragments)."""
+    from . import _capi
+    out = []
+    for i, r in enumerate(records):
+        if r['fg_h'] <= 0 or r['status'] in (_capi.CAND_TRIVIAL, _capi.CAND_ERROR):
+            out.append((np.zeros(2, int), np.zeros((1, 1), bool)))
+            continue
+        r0, c0, h, w = (int(v) for v in mask_info[i])
+        nbytes = ((h * w + 31) // 32) * 4
+        bits = np.unpackbits(masks[mask_offset[i]:mask_offset[i] + nbytes], bitorder='little')[:h * w].reshape(h, w)
+        fr, fc = int(r['fg_r0']) - r0, int(r['fg_c0']) - c0
+        out.append((np.array([int(r['fg_r0']), int(r['fg_c0'])]), bits[fr:fr + int(r['fg_h']), fc:fc + int(r['fg_w'])].astype(bool)))
+    return out
+
+
+class Sharder:
+    """Splits every batch of candidates over the ranks of a process group and all-gathers the results, so that every
+    rank can continue the (cheap, deterministic) host-side generation logic in lock step.
+
+    Per batch: each rank solves its cost-balanced share on its own GPU (no data-path collective), then ONE
+    all-gather of a padded byte block per rank: records (128 B / candidate), mask boxes and the bit-packed masks.
+    """
+
+    def __init__(self, group=None, device=None, solve_local=_gpu_solve_local):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = device
+        self.solve_local = solve_local
+
+    def solve(self, image, footprints, cfg):
+        from . import _capi
+        n = len(footprints)
+        stats = getattr(image, 'atom_stats', None)
+        if stats is not None:
+            area = np.asarray(stats).reshape(-1, 6)[:, 0]
+            costs = [sum(int(area[a]) for a in fp if 0 < a < len(area)) for fp in footprints]
+        else:
+            costs = [len(fp) for fp in footprints]
+        shards = shard_indices(costs, self.world)
+        mine = shards[self.rank]
+        rec_b, info, off, masks = self.solve_local(image, [footprints[i] for i in mine], cfg)
+        payload = np.concatenate([np.asarray(rec_b, np.uint8).reshape(-1), np.ascontiguousarray(info, np.int32).view(np.uint8).reshape(-1),
+                                  np.ascontiguousarray(off, np.int64).view(np.uint8).reshape(-1), np.asarray(masks, np.uint8).reshape(-1)])
+        dev = self.device if self.device is not None else (image.device if hasattr(image, 'device') else 'cpu')
+        size = torch.tensor([payload.size], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(size) for _ in range(self.world)]
+        dist.all_gather(sizes, size, group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        pad = max(sizes)
+        send = torch.zeros(pad, dtype=torch.uint8, device=dev)
+        send[:payload.size] = torch.from_numpy(payload).to(dev)
+        recv = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+        dist.all_gather(recv, send, group=self.group)                 # the one data collective of the batch
+        records = np.zeros(n, _capi.RECORD_DTYPE)
+        fragments = [None] * n
+        for r in range(self.world):
+            idx = shards[r]
+            k = len(idx)
+            buf = recv[r].cpu().numpy()[:sizes[r]]
+            rec = buf[:k * 128].view(_capi.RECORD_DTYPE)
+            inf = buf[k * 128:k * 144].view(np.int32).reshape(k, 4)
+            ofs = buf[k * 144:k * 152].view(np.int64)
+            msk = buf[k * 152:]
+            frs = fragments_from_masks(rec, inf, ofs, msk)
+            for j, i in enumerate(idx):
+                records[i] = rec[j]
+                fragments[i] = frs[j]
+        return records, fragments

@@ -1,0 +1,277 @@
+"""``global-energy-minimization`` stage: Algorithm 1 + Criterion 2 of Kostrykin & Rohr (TPAMI 2023) around the
+batched GPU candidate solver.
+
+Drop-in for the reference stage (superdsm/globalenergymin.py:97-368): same stage name, inputs
+(``y, y_mask, atoms, adjacencies, dsm_cfg``), outputs (``y_img, cover, objects, performance``), hyper-parameters
+(``pruning, beta, max_iter, gamma, max_seed_distance, max_work_amount``) and ``configure_ex`` factors.  The
+generation / pruning logic is host-side bookkeeping and is restated here; every ``compute_objects`` call is one GPU
+batch.
+"""
+import os
+
+import numpy as np
+
+from .image import Image
+from .maxsetpack import solve_maxsetpack
+from .minsetcover import DEFAULT_GAMMA, DEFAULT_MAX_ITER, MinSetCover
+from .objects import Object, compute_objects
+from .output import Text, get_output
+from .pipeline import Stage
+
+DEFAULT_MAX_WORK_AMOUNT = 10 ** 6
+
+
+class PerformanceReport:
+    """Pruning statistics (globalenergymin.py:23-94)."""
+
+    attributes = [
+        'direct_solution_trial_count',
+        'direct_solution_success_count',
+        'iterative_object_count',
+        'iterative_computed_object_count',
+        'overall_object_count',
+        'overall_computed_object_count',
+        'nontrivial_object_count',
+        'nontrivial_computed_object_count',
+    ]
+
+    def __init__(self, **kwargs):
+        for key in self.attributes:
+            setattr(self, key, kwargs.get(key, 0))
+
+    @staticmethod
+    def _ratio(num, den, complement=False):
+        if den == 0:
+            return np.nan
+        return 1 - num / den if complement else num / den
+
+    @property
+    def direct_solution_success(self):
+        return self._ratio(self.direct_solution_success_count, self.direct_solution_trial_count)
+
+    @property
+    def iterative_pruning_success(self):
+        return self._ratio(self.iterative_computed_object_count, self.iterative_object_count, True)
+
+    @property
+    def overall_pruning_success(self):
+        return self._ratio(self.overall_computed_object_count, self.overall_object_count, True)
+
+    @property
+    def nontrivial_pruning_success(self):
+        return self._ratio(self.nontrivial_computed_object_count, self.nontrivial_object_count, True)
+
+    def __iadd__(self, other):
+        for key in self.attributes:
+            setattr(self, key, getattr(self, key) + getattr(other, key))
+        return self
+
+    def _assert_integrity(self):
+        for value in (self.direct_solution_success, self.iterative_pruning_success, self.nontrivial_pruning_success, self.overall_pruning_success):
+            assert np.isnan(value) or 0 <= value <= 1, value
+
+
+def _generation_log_dir(log_root_dir, generation_number):
+    if log_root_dir is None:
+        return None
+    path = os.path.join(log_root_dir, f'gen{generation_number}')
+    os.makedirs(path, exist_ok=True)
+    return path
+
+
+def _within_seed_distance(footprint, new_atom, adjacencies, max_seed_distance):
+    if np.isinf(max_seed_distance):
+        return True
+    seed = np.asarray(adjacencies.get_seed(new_atom))
+    return all(np.linalg.norm(np.asarray(adjacencies.get_seed(a)) - seed) <= max_seed_distance for a in footprint)
+
+
+def _iterate_generation(previous_generation, adjacencies, max_seed_distance, get_footprint=lambda item: item,
+                        ignored_cluster_labels=frozenset(), skip_last=False):
+    """Yields ``(item, new_footprint, new_atom)``: every footprint of the previous generation grown by one adjacent
+    atom, de-duplicated within the generation (globalenergymin.py:292-307)."""
+    seen = set()
+    for item in previous_generation:
+        footprint = get_footprint(item)
+        cluster = adjacencies.get_cluster_label(next(iter(footprint)))
+        if cluster in ignored_cluster_labels:
+            continue
+        if skip_last and len(footprint) + 1 == len(adjacencies.get_atoms_in_cluster(cluster)):
+            continue                                        # the universe is computed separately
+        neighbours = set()
+        for atom in footprint:
+            neighbours |= adjacencies[atom] - footprint
+        for new_atom in neighbours:
+            if not _within_seed_distance(footprint, new_atom, adjacencies, max_seed_distance):
+                continue
+            grown = frozenset(footprint | {new_atom})
+            if grown not in seen:
+                seen.add(grown)
+                yield item, grown, new_atom
+
+
+def _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=DEFAULT_MAX_WORK_AMOUNT,
+                       ignored_cluster_labels=frozenset(), skip_last=False):
+    current = [c.footprint for c in generations[-1]]
+    remaining = 0
+    while current:
+        current = [fp for _, fp, _ in _iterate_generation(current, adjacencies, max_seed_distance,
+                                                          ignored_cluster_labels=ignored_cluster_labels, skip_last=skip_last)]
+        remaining += len(current)
+        if remaining > max_amount:
+            raise ValueError('estimated work amount is too large')
+    return sum(len(gen) for gen in generations), remaining
+
+
+def _process_generation(cover, objects, previous_generation, y, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
+                        log_root_dir, pruning, ignored_cluster_labels, out, shard=None):
+    """One generation: enumerate, prune by the energy bound, solve the survivors as ONE batch, keep those below
+    their threshold (globalenergymin.py:326-368)."""
+    new_objects, thresholds = [], []
+    discarded = 0
+    last_cluster, cluster_costs = None, None
+    for parent, footprint, new_atom in _iterate_generation(previous_generation, adjacencies, max_seed_distance,
+                                                           lambda c: c.footprint, ignored_cluster_labels, skip_last=True):
+        cluster = adjacencies.get_cluster_label(next(iter(parent.footprint)))
+        if cluster != last_cluster:
+            last_cluster, cluster_costs = cluster, cover.get_cluster_costs(cluster)
+        candidate = Object()
+        candidate.footprint = footprint
+        if pruning == 'exact':
+            rest = adjacencies.get_atoms_in_cluster(cluster) - footprint
+            rest_cost = sum(cover.get_atom(a).energy for a in rest)
+            packing = sum(c.energy for c in solve_maxsetpack(
+                [c for c in objects if c.is_optimal and c.footprint.issubset(footprint)], out=out.derive(muted=True)))
+            lower = cover.beta + max(parent.energy + cover.get_atom(new_atom).energy, packing)
+            upper = cluster_costs - rest_cost
+            if upper < lower:
+                discarded += 1
+                continue
+            thresholds.append(upper - cover.beta)
+        elif pruning == 'isbi24':
+            thresholds.append(parent.energy + cover.get_atom(new_atom).energy + cover.beta)
+        else:
+            raise ValueError(f'Unknown pruning mode "{pruning}"')
+        new_objects.append(candidate)
+
+    compute_objects(new_objects, y, atoms_map, dsm_cfg, log_root_dir, out=out, shard=shard)
+
+    next_generation = []
+    for idx, (obj, threshold) in enumerate(zip(new_objects, thresholds)):
+        if obj.energy < threshold:
+            next_generation.append(obj)
+        else:
+            discarded += 1
+            obj.fg_fragment = None                          # only footprint and energy are needed from now on
+        obj.cidx = idx
+    out.write(f'Next iteration: {len(next_generation)} ({discarded} discarded, {pruning} pruning)')
+    return next_generation, new_objects
+
+
+def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, dsm_cfg, beta=np.nan, max_iter=DEFAULT_MAX_ITER,
+                         gamma=DEFAULT_GAMMA, max_seed_distance=np.inf, max_work_amount=DEFAULT_MAX_WORK_AMOUNT, out=None, shard=None):
+    """Returns ``(generations, costs, cover, objects, performance)`` (globalenergymin.py:183-271)."""
+    out = get_output(out)
+
+    atoms = []
+    for label in adjacencies.atom_labels:
+        obj = Object()
+        obj.footprint = {label}
+        atoms.append(obj)
+    out.write('\nIteration 1:')
+    compute_objects(atoms, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 1), out=out, shard=shard)
+    atom_by_label = {next(iter(a.footprint)): a for a in atoms}
+
+    universes = []
+    for cluster in adjacencies.cluster_labels:
+        obj = Object()
+        obj.footprint = set(adjacencies.get_atoms_in_cluster(cluster))
+        universes.append(obj)
+    compute_objects(universes, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 0),
+                    ('Computing universe costs', 'Universe costs computed'), out=out, shard=shard)
+
+    solved_directly, trivial = set(), set()        # Criterion 2 / universes of one or two atoms
+    for cluster, universe in zip(adjacencies.cluster_labels, universes):
+        if len(universe.footprint) <= 2:
+            trivial.add(cluster)
+        members = [atom_by_label[a] for a in adjacencies.get_atoms_in_cluster(cluster)]
+        if all(m.is_optimal for m in members) and universe.energy <= beta + sum(m.energy for m in members):
+            solved_directly.add(cluster)
+
+    cover = MinSetCover(atoms, beta, adjacencies, max_iter=max_iter, gamma=gamma)
+    cover.update(universes, out.derive(muted=True))
+    costs = [cover.costs]
+    out.write(f'Solution costs: {costs[-1]:,g}')
+    out.write(f'Clusters solved directly: {len(solved_directly)} / {len(adjacencies.cluster_labels)}')
+    performance = PerformanceReport(direct_solution_trial_count=len(adjacencies.cluster_labels),
+                                    direct_solution_success_count=len(solved_directly))
+
+    generations = [atoms]
+    objects = atoms + universes
+    progress = lambda ignored: _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=max_work_amount,
+                                                  ignored_cluster_labels=ignored, skip_last=True)
+    performance.nontrivial_object_count = progress(trivial)[1]
+    performance.overall_object_count = performance.nontrivial_object_count + len(objects)
+    performance.iterative_object_count = progress(solved_directly)[1]
+    performance.overall_computed_object_count = len(objects)
+
+    if len(solved_directly) < len(adjacencies.cluster_labels):
+        while True:
+            number = 1 + len(generations)
+            out.write('')
+            done, todo = progress(solved_directly)
+            text = 'progress unknown' if np.isnan(done) or np.isnan(todo) else f'(finished {100 * done / (todo + done):.0f}% or more)'
+            out.write(f'Iteration {number}: {Text.style(text, Text.BOLD)}')
+            new_generation, new_objects = _process_generation(
+                cover, objects, generations[-1], y_img, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
+                _generation_log_dir(log_root_dir, number), pruning, solved_directly, out, shard=shard)
+            objects += new_objects
+            performance.iterative_computed_object_count += len(new_objects)
+            if not new_generation:
+                break
+            generations.append(new_generation)
+            cover.update(new_generation, out.derive(muted=True))
+            costs.append(cover.costs)
+            out.write(f'Solution costs: {costs[-1]:,g}')
+
+    performance.nontrivial_computed_object_count += performance.iterative_computed_object_count
+    performance.overall_computed_object_count += performance.iterative_computed_object_count
+    performance._assert_integrity()
+    out.write('')
+    out.write(f'Non-trivial pruning: {100 * performance.nontrivial_pruning_success:.1f}% '
+              f'(computed {performance.nontrivial_computed_object_count} / {performance.nontrivial_object_count})')
+    return generations, costs, cover, objects, performance
+
+
+class GlobalEnergyMinimization(Stage):
+    """Stage ``global-energy-minimization``.  ``shard`` (optional): a :class:`superdsm_amd.dist.Sharder` that splits
+    every batch of candidates over the ranks of a process group."""
+
+    ENABLED_BY_DEFAULT = True
+
+    def __init__(self, shard=None):
+        super().__init__('global-energy-minimization',
+                         inputs=['y', 'y_mask', 'atoms', 'adjacencies', 'dsm_cfg'],
+                         outputs=['y_img', 'cover', 'objects', 'performance'])
+        self.shard = shard
+
+    def process(self, input_data, cfg, out, log_root_dir):
+        y_img = Image.create_from_array(input_data['y'], normalize=False, mask=input_data['y_mask'])
+        pruning = cfg.get('pruning', 'exact')
+        beta = cfg.get('beta', 0)
+        max_iter = cfg.get('max_iter', DEFAULT_MAX_ITER)
+        gamma = cfg.get('gamma', DEFAULT_GAMMA)
+        max_seed_distance = cfg.get('max_seed_distance', np.inf)
+        max_work_amount = cfg.get('max_work_amount', DEFAULT_MAX_WORK_AMOUNT)
+        assert 0 < gamma < 1
+        assert pruning in ('exact', 'isbi24')
+        _, _, cover, objects, performance = _compute_generations(
+            input_data['adjacencies'], y_img, input_data['atoms'], log_root_dir, pruning, dict(input_data['dsm_cfg']),
+            beta, max_iter, gamma, max_seed_distance, max_work_amount, out, shard=self.shard)
+        return {'y_img': y_img, 'cover': cover, 'objects': objects, 'performance': performance}
+
+    def configure_ex(self, scale, radius, diameter):
+        return {
+            'beta': (scale ** 2, 0.66),
+            'max_seed_distance': (diameter, np.inf),
+        }

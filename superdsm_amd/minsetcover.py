@@ -1,0 +1,106 @@
+"""Approximate min-weight set cover on the host (reference: superdsm/minsetcover.py:4-164, Algorithm 2 of
+Kostrykin & Rohr, TPAMI 2023), restated.  Stays on the CPU by design (BASELINE.json north_star)."""
+from .output import get_output
+
+DEFAULT_MAX_ITER = 5
+DEFAULT_GAMMA = 0.8
+
+
+def _greedy_cover(objects, beta):
+    """Greedy phase: repeatedly accept the object with the lowest price (energy + beta) / #newly covered atoms;
+    ties are resolved in favour of the object that comes first in ``objects``."""
+    uncovered = set().union(*(c.footprint for c in objects))
+    candidates = list(objects)
+    accepted = []
+    while candidates:
+        best = min(candidates, key=lambda c: (c.energy + beta) / len(c.footprint & uncovered))
+        accepted.append(best)
+        uncovered -= best.footprint
+        candidates = [c for c in candidates if c.footprint & uncovered]
+    return accepted
+
+
+def _merge_phase(objects, accepted, beta):
+    """Merge phase: a not-yet-accepted object replaces the accepted objects it fully contains if that is cheaper."""
+    replaced = 0
+    cost = lambda c: c.energy + beta
+    for new in sorted((c for c in objects if c not in accepted), key=cost):
+        inside = []
+        for c in accepted:
+            common = len(c.footprint & new.footprint)
+            if common == 0:
+                continue
+            if common < len(c.footprint):
+                inside = None                       # partial overlap: not a valid replacement
+                break
+            inside.append(c)
+        if inside is None:
+            continue
+        if cost(new) < sum(cost(c) for c in inside):
+            replaced += len(inside)
+            accepted = [c for c in accepted if c not in inside] + [new]
+    return accepted, replaced
+
+
+def _solve_once(objects, beta, merge, out):
+    accepted = _greedy_cover(objects, beta)
+    out.write(f'MINSETCOVER - GREEDY accepted objects: {len(accepted)}')
+    if merge:
+        accepted, replaced = _merge_phase(objects, accepted, beta)
+        out.write(f'MINSETCOVER - MERGED objects: {replaced}')
+    return accepted
+
+
+def solve_minsetcover(objects, beta, merge=True, max_iter=DEFAULT_MAX_ITER, gamma=DEFAULT_GAMMA, out=None):
+    """Cover for ``beta``; retried with ``beta * gamma`` (up to ``max_iter`` levels), keeping a retry only if it is
+    cheaper when priced with the ORIGINAL beta of the level that spawned it."""
+    assert beta >= 0 and 0 < gamma < 1
+    out = get_output(out)
+    solution = _solve_once(objects, beta, merge, out)
+    if max_iter > 1 and beta > 0:
+        out.write(f'MINSETCOVER retry with lower beta: {beta * gamma:g}')
+        retry = solve_minsetcover(objects, beta * gamma, merge, max_iter - 1, gamma, out)
+        price = lambda sol: sum(c.energy for c in sol) + beta * len(sol)
+        if price(retry) < price(solution):
+            return retry
+    return solution
+
+
+class MinSetCover:
+    """Incrementally maintained per-cluster covers (minsetcover.py:91-164)."""
+
+    def __init__(self, atoms, beta, adjacencies, **solve_minsetcover_kwargs):
+        label_of = lambda atom: next(iter(atom.footprint))
+        for atom in atoms:
+            assert len(atom.footprint) == 1
+        self.atoms = {label_of(atom): atom for atom in atoms}
+        self.beta = beta
+        self.adjacencies = adjacencies
+        self.solve_minsetcover_kwargs = solve_minsetcover_kwargs
+        self.objects_by_cluster = {cl: [a for a in atoms if adjacencies.get_cluster_label(label_of(a)) == cl] for cl in adjacencies.cluster_labels}
+        self.solution_by_cluster = {cl: self.objects_by_cluster[cl] for cl in adjacencies.cluster_labels}
+
+    def get_atom(self, atom_label):
+        return self.atoms[atom_label]
+
+    def update(self, new_objects, out=None):
+        touched = set()
+        for obj in new_objects:
+            cl = self.adjacencies.get_cluster_label(next(iter(obj.footprint)))
+            self.objects_by_cluster[cl].append(obj)
+            touched.add(cl)
+        for cl in touched:
+            self.solution_by_cluster[cl] = solve_minsetcover(self.objects_by_cluster[cl], self.beta, out=out, **self.solve_minsetcover_kwargs)
+
+    def get_cluster_costs(self, cluster_label):
+        sol = self.solution_by_cluster[cluster_label]
+        return sum(c.energy for c in sol) + self.beta * len(sol)
+
+    @property
+    def solution(self):
+        return [c for sol in self.solution_by_cluster.values() for c in sol]
+
+    @property
+    def costs(self):
+        sol = self.solution
+        return sum(c.energy for c in sol) + self.beta * len(sol)

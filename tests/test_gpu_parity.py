@@ -249,3 +249,68 @@ def test_preprocess_matches_reference(gpu, key):
     cfg = json.loads(str(d['cfg']))
     y = engine.preprocess(d['g_raw'], cfg.get('sigma1', np.sqrt(2)), cfg.get('sigma2', 40), cfg.get('offset_clip', 3), cfg.get('lower_clip_mean', False))
     np.testing.assert_allclose(y, d['y'], rtol=0, atol=1e-13)     # tolerance: fp64 re-association in mean / std only
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the stage behind the reference's plugin API (globalenergymin.py:97-180)
+# ---------------------------------------------------------------------------------------------------------
+def test_stage_end_to_end_matches_cpu_oracle(gpu, monkeypatch):
+    """GlobalEnergyMinimization.process on the GPU vs the same generation logic driven by the CPU oracle: same
+    batches of candidates, same min-weight set cover, same masks."""
+    from oracle import oracle
+    from superdsm_amd import config, globalenergymin, objects, testing
+    scene = testing.make_scene('synthetic256', max_size=2)
+    beta = 150.0
+    stage = globalenergymin.GlobalEnergyMinimization()
+    data = dict(y=scene['y'], y_mask=np.ones(scene['y'].shape, bool), atoms=scene['atoms'], adjacencies=scene['adjacencies'], dsm_cfg=scene['dsm_cfg'])
+    cfg = config.Config({'global-energy-minimization': {'beta': beta, 'pruning': 'exact'}})
+    gpu_batches = []
+    real = objects.compute_objects
+
+    def spy(objs, *a, **k):
+        objs = list(objs)
+        gpu_batches.append(sorted(sorted(o.footprint) for o in objs))
+        return real(objs, *a, **k)
+
+    monkeypatch.setattr(globalenergymin, 'compute_objects', spy)
+    stage(data, cfg, out='muted')
+    cover_gpu = sorted(sorted(int(a) for a in o.footprint) for o in data['cover'].solution)
+    costs_gpu = data['cover'].costs
+
+    cpu_batches = []
+
+    def oracle_compute(objs, y, atoms, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None):
+        objs = list(objs)
+        cpu_batches.append(sorted(sorted(o.footprint) for o in objs))
+        if not objs:
+            return
+        recs, frags, _ = oracle.compute_objects(y.model, None, atoms, [sorted(o.footprint) for o in objs], dsm_cfg, nthreads=0)
+        for o, r, f in zip(objs, recs, frags):
+            o.energy, o.is_optimal, o.on_boundary, o.processing_time = float(r['energy']), bool(r['is_optimal']), bool(r['on_boundary']), 0
+            o.fg_offset, o.fg_fragment = np.array(r['fg_offset']), f
+
+    monkeypatch.setattr(globalenergymin, 'compute_objects', oracle_compute)
+    data2 = dict(data)
+    stage(data2, cfg, out='muted')
+    assert gpu_batches == cpu_batches
+    assert cover_gpu == sorted(sorted(int(a) for a in o.footprint) for o in data2['cover'].solution)
+    assert abs(costs_gpu - data2['cover'].costs) <= 1e-5 * abs(costs_gpu)
+    for k in data['performance'].attributes:
+        assert getattr(data['performance'], k) == getattr(data2['performance'], k)
+    seg_gpu = np.zeros(scene['y'].shape, bool)
+    seg_cpu = np.zeros(scene['y'].shape, bool)
+    for o in data['cover'].solution:
+        o.fill_foreground(seg_gpu)
+    for o in data2['cover'].solution:
+        o.fill_foreground(seg_cpu)
+    dice = 2 * (seg_gpu & seg_cpu).sum() / max(1, seg_gpu.sum() + seg_cpu.sum())
+    assert dice >= 0.999, dice
+
+
+def test_preprocess_stage_in_pipeline(gpu):
+    from superdsm_amd import config, pipeline
+    from superdsm_amd.preprocess import Preprocessing
+    d = np.load(os.path.join(G, 'preprocess_a.npz'))
+    pl = pipeline.create_pipeline([Preprocessing()])
+    data, _, _ = pl.process_image(d['g_raw'], config.Config({'preprocess': json.loads(str(d['cfg']))}), out='muted')
+    np.testing.assert_allclose(data['y'], d['y'], rtol=0, atol=1e-13)

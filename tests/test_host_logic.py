@@ -1,0 +1,206 @@
+"""Host-side mirror of the reference's plugin API against literal known-answer tests of the reference
+(tests/test_objects.py, tests/test_image.py, tests/test_atoms.py) and golden vectors produced by running the
+reference (tests/golden/config.json, setcover.json).  CPU only; the GPU solver is replaced by the fixture's energy table."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from superdsm_amd import atoms as sd_atoms
+from superdsm_amd import automation, config, globalenergymin, image, maxsetpack, minsetcover, objects, pipeline
+from superdsm_amd.dsmcfg import DSM_Config
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+# ---- reference KATs: tests/test_objects.py:11-50 ---------------------------------------------------------
+def test_fill_foreground_kat():
+    obj = objects.BaseObject()
+    obj.fg_fragment = np.array([[False, True], [True, True], [True, False]])
+    obj.fg_offset = (1, 2)
+    actual = np.zeros((4, 5), bool)
+    obj.fill_foreground(actual)
+    expected = np.array([[0, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 0, 1, 1, 0], [0, 0, 1, 0, 0]], bool)
+    np.testing.assert_array_equal(actual, expected)
+
+
+def test_get_mask_kat():
+    atoms = np.array([[1, 1, 2], [1, 3, 2], [3, 3, 3]])
+    obj = objects.Object()
+    obj.footprint = {2, 3}
+    np.testing.assert_array_equal(obj.get_mask(atoms), np.array([[0, 0, 1], [0, 1, 1], [1, 1, 1]], bool))
+
+
+def test_extract_foreground_fragment_kat():
+    mask = np.array([[0, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 0, 1, 1, 0], [0, 0, 1, 0, 0]], bool)
+    off, frag = objects.extract_foreground_fragment(mask)
+    np.testing.assert_array_equal(off, [1, 2])
+    np.testing.assert_array_equal(frag, np.array([[0, 1], [1, 1], [1, 0]], bool))
+    off, frag = objects.extract_foreground_fragment(np.zeros((3, 3), bool))
+    np.testing.assert_array_equal(off, [0, 0])
+    np.testing.assert_array_equal(frag, [[False]])
+
+
+# ---- reference KATs: tests/test_image.py:10-40 -------------------------------------------------------------
+def test_get_pixel_map_kat():
+    expected = np.array([np.repeat(np.arange(5.0)[:, None], 5, 1), np.repeat(np.arange(5.0)[None, :], 5, 0)])
+    np.testing.assert_allclose(image.get_pixel_map((5, 5)), expected)
+    np.testing.assert_allclose(image.get_pixel_map((5, 5), normalized=True), expected / 4)
+
+
+def test_bbox_kat():
+    mask = np.array([[0, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 0, 1, 1, 0], [0, 0, 1, 0, 0]], bool)
+    b1, s1 = image.bbox(mask)
+    b2, s2 = image.bbox(mask, include_end=True)
+    np.testing.assert_array_equal(b1, [[1, 4], [2, 4]])
+    np.testing.assert_array_equal(b2, [[1, 3], [2, 3]])
+    assert s1 == (slice(1, 4, None), slice(2, 4, None)) and s2 == (slice(1, 3, None), slice(2, 3, None))
+
+
+# ---- reference KATs: tests/test_atoms.py:12-69 -------------------------------------------------------------
+@pytest.fixture(scope='module')
+def kat_graph():
+    atoms = np.array([[1, 1, 2, 4], [1, 3, 2, 4], [3, 3, 3, 4]])
+    clusters = np.array([[1, 1, 2, 2], [1, 2, 2, 2], [2, 2, 2, 2]])
+    fg = np.array([[1, 0, 1, 0], [1, 0, 1, 1], [1, 1, 1, 1]], bool)
+    seeds = [(0, 0), (0, 2), (2, 1), (1, 3)]
+    return sd_atoms.AtomAdjacencyGraph(atoms, clusters, fg, seeds), sd_atoms.AtomAdjacencyGraph(atoms, clusters, fg, seeds[::-1])
+
+
+def test_adjacency_graph_kat(kat_graph):
+    adj, adj_rev = kat_graph
+    assert adj[1] == set() and adj[2] == {3, 4} and adj[3] == {2, 4} and adj[4] == {2, 3}
+    assert adj.atom_labels == frozenset({1, 2, 3, 4}) and adj.cluster_labels == frozenset({1, 2})
+    assert [adj.get_atom_degree(a) for a in (1, 2, 3, 4)] == [0, 2, 2, 2] and adj.max_degree == 2
+    assert adj.get_atoms_in_cluster(1) == {1} and adj.get_atoms_in_cluster(2) == {2, 3, 4}
+    assert [adj.get_cluster_label(a) for a in (1, 2, 3, 4)] == [1, 2, 2, 2]
+    assert adj.get_edge_lines() == [((0, 2), (2, 1)), ((0, 2), (1, 3)), ((2, 1), (1, 3))]
+    assert adj.get_edge_lines(lambda i: i != 4) == [((0, 2), (2, 1))]
+    assert adj.get_edge_lines(lambda i: i != 4, reduce=False) == [((0, 2), (2, 1)), ((2, 1), (0, 2))]
+    for g in (adj, adj_rev):
+        assert [g.get_seed(a) for a in (1, 2, 3, 4)] == [(0, 0), (0, 2), (2, 1), (1, 3)]
+
+
+# ---- Config semantics (superdsm/config.py) -----------------------------------------------------------------
+def test_config_semantics():
+    cfg = config.Config()
+    assert cfg.get('a/b/c', 5) == 5 and cfg.entries == {'a': {'b': {'c': 5}}}          # get inserts the default
+    cfg['a/b/d'] = None
+    assert cfg.set_default('a/b/d', 7) is None and cfg.set_default('a/b/d', 7, override_none=True) == 7
+    assert 'a/b' in cfg and 'a/x' not in cfg and cfg['a/b/c'] == 5
+    other = cfg.derive(config.Config({'a': {'b': {'c': 6}}, 'z': 1}))
+    assert other['a/b/c'] == 6 and other['z'] == 1 and cfg['a/b/c'] == 5
+    assert cfg.pop('a/b/c', None) == 5 and 'a/b/c' not in cfg
+    assert config.Config(cfg).entries is not cfg.entries and config.Config(cfg.entries).entries is cfg.entries
+    assert cfg.md5.hexdigest() == config.Config(cfg).md5.hexdigest()
+
+
+def test_af_expansion_matches_reference():
+    """AF_ rule (automation.py:71-102) on the dataset task specs, against the reference's own create_config."""
+    from superdsm_amd.globalenergymin import GlobalEnergyMinimization
+    from superdsm_amd.preprocess import Preprocessing
+    golden = json.load(open(os.path.join(G, 'config.json')))
+    pl = pipeline.Pipeline()
+    for st in (Preprocessing(), DSM_Config(), GlobalEnergyMinimization()):
+        pl.append(st)
+    for key, case in golden.items():
+        cfg, scale = automation.create_config(pl, config.Config(json.loads(json.dumps(case['base']))))
+        assert scale == case['scale']
+        assert json.loads(json.dumps(cfg.entries)) == case['expanded'], key
+
+
+def test_pipeline_ordering_and_contract():
+    class A(pipeline.Stage):
+        def __init__(self):
+            super().__init__('a', inputs=['g_raw'], outputs=['x'])
+
+        def process(self, input_data, cfg, out, log_root_dir):
+            return {'x': input_data['g_raw'].sum()}
+
+    class B(pipeline.Stage):
+        def __init__(self):
+            super().__init__('b', inputs=['x'], outputs=['z'])
+
+        def process(self, input_data, cfg, out, log_root_dir):
+            return {'z': input_data['x'] * cfg.get('factor', 2)}
+
+    pl = pipeline.create_pipeline([B(), A()])
+    assert [s.name for s in pl.stages] == ['a', 'b']
+    data, cfg, timings = pl.process_image(np.array([[0.0, 2.0], [4.0, 4.0]]), config.Config({'b': {'factor': 3}}), out='muted')
+    assert data['z'] == pytest.approx(3 * 2.5) and set(timings) == {'a', 'b'}      # g_raw is min-max normalised first
+    data2, _, t2 = pl.process_image(None, config.Config(), first_stage='b', data=dict(data), out='muted')
+    assert set(t2) == {'b'} and data2['z'] == pytest.approx(2 * 2.5)
+    with pytest.raises(ValueError):
+        pipeline.create_pipeline([B()])
+    from superdsm_amd.globalenergymin import GlobalEnergyMinimization
+    st = GlobalEnergyMinimization()
+    assert st.name == 'global-energy-minimization' and set(st.inputs) == {'y', 'y_mask', 'atoms', 'adjacencies', 'dsm_cfg'}
+    assert set(st.outputs) == {'y_img', 'cover', 'objects', 'performance'}
+    assert st.configure(40) == {'beta': (1600, 0.66), 'max_seed_distance': (pytest.approx(2 * 40 * np.sqrt(2)), np.inf)}
+
+
+# ---- set cover / set packing / generation logic against the reference run on a fake energy table ------------
+@pytest.fixture(scope='module')
+def setcover_fixture():
+    d = json.load(open(os.path.join(G, 'setcover.json')))
+    scene = np.load(os.path.join(G, 'setcover_scene.npz'))
+    shape = tuple(int(v) for v in scene['shape'])
+    fg = np.unpackbits(scene['fg'])[:shape[0] * shape[1]].reshape(shape).astype(bool)
+    adj = sd_atoms.AtomAdjacencyGraph(scene['atoms'], scene['clusters'], fg, [tuple(s) for s in scene['seeds']])
+    return d, adj, scene['atoms']
+
+
+def test_adjacency_matches_reference(setcover_fixture):
+    d, adj, _ = setcover_fixture
+    ref = d['adjacency']
+    assert sorted(adj.atom_labels) == ref['atom_labels'] and sorted(adj.cluster_labels) == ref['cluster_labels']
+    for a in ref['atom_labels']:
+        assert sorted(adj[a]) == ref['adjacency'][str(a)]
+        assert adj.get_cluster_label(a) == ref['cluster_of_atom'][str(a)]
+        assert list(adj.get_seed(a)) == ref['seeds'][str(a)]
+
+
+class _Fake:
+    def __init__(self, fp, energy):
+        self.footprint, self.energy, self.is_optimal = set(fp), energy, True
+
+
+def test_minsetcover_and_maxsetpack_match_reference(setcover_fixture):
+    d, adj, _ = setcover_fixture
+    from superdsm_amd import synth
+    table = d['energy_table']
+    cands = [fp for fp in synth.enumerate_candidates(adj, max_size=4) if len(fp) <= 3]
+    fam = [_Fake(fp, table[','.join(map(str, fp))]) for fp in cands]
+    for key, expected in d['minsetcover'].items():
+        sol = minsetcover.solve_minsetcover(fam, float(key[4:]), out='muted')
+        assert sorted(sorted(c.footprint) for c in sol) == expected
+    assert sorted(sorted(c.footprint) for c in maxsetpack.solve_maxsetpack(fam, out='muted')) == d['maxsetpack']
+
+
+@pytest.mark.parametrize('case', ['beta0_exact', 'beta0_isbi24', 'beta60_exact', 'beta60_isbi24', 'beta150_exact', 'beta150_isbi24'])
+def test_generations_match_reference(setcover_fixture, case, monkeypatch):
+    """Same batches, same pruning decisions, same cover and the same PerformanceReport as the reference's
+    _compute_generations when both are fed the same energies."""
+    d, adj, atoms = setcover_fixture
+    table = d['energy_table']
+    expected = d['generations'][case]
+    beta, pruning = float(case.split('_')[0][4:]), case.split('_')[1]
+    batches = []
+
+    def fake_compute_objects(objs, y, atoms_map, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None):
+        objs = list(objs)
+        batches.append([sorted(int(a) for a in o.footprint) for o in objs])
+        for o in objs:
+            o.energy = table[','.join(map(str, sorted(o.footprint)))]
+            o.is_optimal, o.on_boundary, o.processing_time = True, False, 0
+            o.fg_offset, o.fg_fragment = np.zeros(2, int), np.zeros((1, 1), bool)
+
+    monkeypatch.setattr(globalenergymin, 'compute_objects', fake_compute_objects)
+    gens, costs, cover, objs, perf = globalenergymin._compute_generations(adj, None, atoms, None, pruning, {}, beta=beta, out='muted')
+    assert [sorted(b) for b in batches] == [sorted(b) for b in expected['batches']]
+    np.testing.assert_allclose(costs, expected['costs'], rtol=1e-12)
+    assert sorted(sorted(int(a) for a in o.footprint) for o in cover.solution) == expected['solution']
+    assert len(objs) == expected['n_objects']
+    assert {k: int(getattr(perf, k)) for k in perf.attributes} == expected['performance']
+    assert [sorted(sorted(int(a) for a in o.footprint) for o in g) for g in gens] == [sorted(g) for g in expected['generations']]
