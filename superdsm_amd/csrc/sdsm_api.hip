@@ -269,9 +269,10 @@ static thread_local long long *g_prof = nullptr;
 // Diagnostic builds (-DSDSM_PROFILE): device buffer of 8 int64 cycle counters per candidate, see DESIGN.md.
 extern "C" int sdsm_set_debug_buffer(void *d_buf) { g_prof = (long long *)d_buf; return SDSM_OK; }
 
-// side streams / fork-join events of the three solve classes (created on first use, per host thread)
-static thread_local hipStream_t g_side[2] = {nullptr, nullptr};
-static thread_local hipEvent_t g_fj[3] = {nullptr, nullptr, nullptr};
+// side streams / fork-join events of the three solve classes: one set per caller stream (created on first use, per
+// host thread), so that batches queued on different streams overlap instead of serialising on shared side streams
+struct SideSet { hipStream_t side[2]; hipEvent_t fj[3]; };
+static thread_local std::vector<std::pair<hipStream_t, SideSet>> g_sides;
 
 static thread_local int g_timing = 0;
 static thread_local hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
@@ -322,11 +323,16 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     if ((e = sdsm_launch_setup(P, d_y, d_atoms, d_valid, s)) != hipSuccess) return hipfail(e, "launch setup");
     if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    if (!g_side[0]) {
-        for (int i = 0; i < 2; i++) if ((e = hipStreamCreateWithFlags(&g_side[i], hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
-        for (int i = 0; i < 3; i++) if ((e = hipEventCreateWithFlags(&g_fj[i], hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
+    SideSet *ss = nullptr;
+    for (auto &kv : g_sides) if (kv.first == s) ss = &kv.second;
+    if (!ss) {
+        SideSet n{};
+        for (int i = 0; i < 2; i++) if ((e = hipStreamCreateWithFlags(&n.side[i], hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
+        for (int i = 0; i < 3; i++) if ((e = hipEventCreateWithFlags(&n.fj[i], hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
+        g_sides.emplace_back(s, n);
+        ss = &g_sides.back().second;
     }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, g_side[0], g_side[1], g_fj)) != hipSuccess) return hipfail(e, "launch solve");
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], ss->fj)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }

@@ -443,6 +443,64 @@ __device__ __forceinline__ bool factor_solve(const Cand &c, int n, double *lam2)
     __syncthreads();
     if (*flag) return false;
 
+    if (n == 6) {
+        // ---- elliptical model: 6 x 6 system solved redundantly by every thread in registers (no barriers) ----
+        double A[6][6], bb[6], s6[6], z[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) s6[i] = sc[i];
+        double tau = 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 12 && !ok; attempt++) {
+            ok = true;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int k = 0; k <= i; k++) A[i][k] = Hp[tri(i, k)] * s6[i] * s6[k] + (i == k ? tau : 0.0);
+                bb[i] = -g[i] * s6[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                double piv = A[j][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) piv -= A[j][k] * A[j][k];
+                if (!(piv > 1e-300) || !isfinite(piv)) { ok = false; piv = 1; }
+                const double ljj = sqrt(piv);
+                A[j][j] = ljj;
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) {
+                    double v = A[i][j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) v -= A[i][k] * A[j][k];
+                    A[i][j] = v / ljj;
+                }
+                double v = bb[j];
+#pragma unroll
+                for (int k = 0; k < j; k++) v -= z[k] * A[j][k];
+                z[j] = v / ljj;                                   // forward substitution rides along
+            }
+            if (!ok) tau = tau == 0 ? 1e-12 : tau * 100;
+        }
+        if (!ok) return false;
+        double l2 = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) l2 += z[i] * z[i];
+#pragma unroll
+        for (int k = 5; k >= 0; k--) {                            // back substitution
+            double v = z[k];
+#pragma unroll
+            for (int m = k + 1; m < 6; m++) v -= A[m][k] * z[m];
+            z[k] = v / A[k][k];
+        }
+        bool fin = isfinite(l2);
+#pragma unroll
+        for (int i = 0; i < 6; i++) { z[i] *= s6[i]; if (!isfinite(z[i])) fin = false; }
+        if (!fin) return false;                                   // uniform: every thread computed the same values
+        if (tid < 6) d[tid] = z[tid];
+        __syncthreads();
+        *lam2 = l2;
+        return true;
+    }
+
     const int ri = tid >> 4, ki = tid & 15;                   // 16 x 16 thread grid over the trailing sub-matrix
     double tau = 0;
     bool ok = false;
@@ -522,8 +580,8 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
     int status = 1, iters = 0;
     for (;;) {
         double psi;
-        if (DENSE) psi = eval_full_dense<L, B>(c, M PROF_ARG);
-        else psi = eval_full_sparse<L>(c, M PROF_ARG);
+        if (DENSE && M > 0) psi = eval_full_dense<L, B>(c, M PROF_ARG);
+        else psi = eval_full_sparse<L>(c, M PROF_ARG);       // M == 0: 28 register sums, no LDS staging, no atomics
         (*ev_full)++;
         long long pt = PROF_NOW();
         double f = c.scale * psi;
@@ -535,8 +593,19 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         iters++;
         PROF_ADD(3, pt);
         if (lam2 * 0.5 <= NEWTON_ABSTOL + NEWTON_RELTOL * fabs(f)) {
-            for (int i = tid; i < n; i += SDSM_WG) x[i] += d[i];          // final full step
+            // converged: final full step, kept only if it does not increase f (near-separable regions have a
+            // vanishing Hessian and the unguarded step can be arbitrarily bad)
+            for (int i = tid; i < n; i += SDSM_WG) xt[i] = x[i] + d[i];
             __syncthreads();
+            const double psit = eval_value<L>(c, L::XT, M);
+            (*ev_value)++;
+            if (isfinite(psit) && c.scale * psit <= f) {
+                for (int i = tid; i < n; i += SDSM_WG) x[i] = xt[i];
+                __syncthreads();
+                *psi_out = psit;
+                *iters_out = iters;
+                return 0;
+            }
             status = 0;
             break;
         }
