@@ -173,7 +173,7 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M)
 // DENSE full evaluation (n <= 40): Jacobian rows staged in LDS, register-tiled float64 accumulation.
 // ---------------------------------------------------------------------------------------------------------
 template <class L, int B>
-__device__ __forceinline__ double eval_full_dense(const Cand &c, int M PROF_PARAM)
+__device__ __noinline__ double eval_full_dense(const Cand &c, int M PROF_PARAM)
 {
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
@@ -306,7 +306,12 @@ __device__ __forceinline__ double eval_full_dense(const Cand &c, int M PROF_PARA
         }
     }
     block_sum_vec<7>(red, SD + L::RED);
-    if (tid < 6) g[tid] = red[1 + tid];
+    if (tid < 6) {
+        double gv = 0;
+#pragma unroll
+        for (int e = 0; e < 6; e++) gv = tid == e ? red[1 + e] : gv;
+        g[tid] = gv;
+    }
     __syncthreads();
     double psi = red[0];
     if (M > 0) psi += add_regulariser<L>(c, M);
@@ -316,10 +321,59 @@ __device__ __forceinline__ double eval_full_dense(const Cand &c, int M PROF_PARA
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// ELLIPTICAL full evaluation (M = 0, n = 6): psi, 6 gradient entries and the 21 entries of the 6x6 Hessian are
+// per-lane register sums over the lane's pixels, reduced with wavefront shuffles + one LDS hop.
+// ---------------------------------------------------------------------------------------------------------
+template <class L>
+__device__ __noinline__ double eval_full_ell(const Cand &c PROF_PARAM)
+{
+    long long pt = PROF_NOW();
+    const int tid = threadIdx.x;
+    double *Hp = SD + L::HP, *g = SD + L::G;
+    const double *xv = SD + L::X;
+    double red[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) red[k] = 0;
+    for (int p = tid; p < c.N; p += SDSM_WG) {
+        const double yv = c.crop_y[p];
+        const uint32_t rc = c.crop_rc[p];
+        const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
+        const double q[6] = {u * u, v * v, 2 * (u * v), 2 * u, 2 * v, 1.0};
+        const double Sv = q[0] * xv[0] + q[1] * xv[1] + q[2] * xv[2] + q[3] * xv[3] + q[4] * xv[4] + xv[5];
+        double phi, r, dc;
+        loss_terms(yv, Sv, &phi, &r, &dc);
+        red[0] += phi;
+#pragma unroll
+        for (int a = 0; a < 6; a++) red[1 + a] += r * q[a];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) red[7 + a * (a + 1) / 2 + b] += dc * q[a] * q[b];   // static index: stays in registers
+    }
+    PROF_ADD(0, pt);
+    block_sum_vec<28>(red, SD + L::RED);
+    if (tid < 6) {
+        double gv = 0;
+#pragma unroll
+        for (int e = 0; e < 6; e++) gv = tid == e ? red[1 + e] : gv;
+        g[tid] = gv;
+    }
+    if (tid < 21) {
+        double hv = 0;
+#pragma unroll
+        for (int e = 0; e < 21; e++) hv = tid == e ? red[7 + e] : hv;     // select instead of a dynamic register index
+        Hp[tid] = hv;
+    }          // packed lower triangle of a 6x6 matrix = the same enumeration order
+    __syncthreads();
+    PROF_ADD(2, pt);
+    return red[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // SPARSE full evaluation (n > 40): per-pixel products added into the packed Hessian in LDS (ds_add_f64).
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __forceinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
+__device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
 {
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
@@ -361,13 +415,10 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M PROF_PAR
         red[0] += phi;
 #pragma unroll
         for (int a = 0; a < 6; a++) red[1 + a] += r * q[a];
-        {
-            int e = 7;
 #pragma unroll
-            for (int a = 0; a < 6; a++)
+        for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int b = 0; b <= a; b++) red[e++] += dc * q[a] * q[b];
-        }
+            for (int b = 0; b <= a; b++) red[7 + a * (a + 1) / 2 + b] += dc * q[a] * q[b];
         if (dc != 0 || r != 0) {
             if (in_regs) {
 #pragma unroll
@@ -398,11 +449,17 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M PROF_PAR
     }
     PROF_ADD(0, pt);
     block_sum_vec<28>(red, SD + L::RED);
-    if (tid < 6) g[tid] = red[1 + tid];
+    if (tid < 6) {
+        double gv = 0;
+#pragma unroll
+        for (int e = 0; e < 6; e++) gv = tid == e ? red[1 + e] : gv;
+        g[tid] = gv;
+    }
     if (tid < 21) {
-        int a = 0;
-        while ((a + 1) * (a + 2) / 2 <= tid) a++;
-        Hp[tri(a, tid - a * (a + 1) / 2)] = red[7 + tid];
+        double hv = 0;
+#pragma unroll
+        for (int e = 0; e < 21; e++) hv = tid == e ? red[7 + e] : hv;
+        Hp[tid] = hv;                                    // rows 0..5 of the packed triangle are its first 21 entries
     }
     __syncthreads();
     double psi = red[0];
@@ -419,7 +476,7 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M PROF_PAR
 // INPLACE: the factor overwrites the Hessian; a copy is kept in global memory (c.hsave) for retries.
 // ---------------------------------------------------------------------------------------------------------
 template <class L, bool INPLACE>
-__device__ __forceinline__ bool factor_solve(const Cand &c, int n, double *lam2)
+__device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
 {
     const int tid = threadIdx.x;
     const int np = n * (n + 1) / 2;
@@ -501,12 +558,13 @@ __device__ __forceinline__ bool factor_solve(const Cand &c, int n, double *lam2)
         return true;
     }
 
-    const int ri = tid >> 4, ki = tid & 15;                   // 16 x 16 thread grid over the trailing sub-matrix
+    // ---- general case: all 256 threads, 16 x 16 thread grid over the trailing sub-matrix, 2 barriers per column.
+    //      (A single-wave variant without s_barrier was measured slower: 61 vs 46 us at n = 50, 249 vs 142 us at n = 90.)
+    const int ri = tid >> 4, ki = tid & 15;
     double tau = 0;
     bool ok = false;
     for (int attempt = 0; attempt < 12 && !ok; attempt++) {
-        // scaled copy: thread grid over (row, column)
-        for (int i = ri; i < n; i += 16) {
+        for (int i = ri; i < n; i += 16) {                        // scaled copy
             const double si = sc[i];
             for (int k = ki; k <= i; k += 16) {
                 double v = (INPLACE ? c.hsave[tri(i, k)] : Hp[tri(i, k)]) * si * sc[k];
@@ -580,8 +638,9 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
     int status = 1, iters = 0;
     for (;;) {
         double psi;
-        if (DENSE && M > 0) psi = eval_full_dense<L, B>(c, M PROF_ARG);
-        else psi = eval_full_sparse<L>(c, M PROF_ARG);       // M == 0: 28 register sums, no LDS staging, no atomics
+        if (M == 0) psi = eval_full_ell<L>(c PROF_ARG);
+        else if constexpr (DENSE) psi = eval_full_dense<L, B>(c, M PROF_ARG);
+        else psi = eval_full_sparse<L>(c, M PROF_ARG);
         (*ev_full)++;
         long long pt = PROF_NOW();
         double f = c.scale * psi;
