@@ -121,7 +121,7 @@ struct sdsm_plan {
     std::vector<int64_t> mask_off_bytes, xi_off;
     int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hsave = 0;
     size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0,
-           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_ell_nnz = 0, off_psf = 0, off_hsave = 0, total = 0;
+           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_ell_nnz = 0, off_ell_hnz = 0, off_psf = 0, off_hsave = 0, total = 0;
 };
 
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -210,6 +210,7 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->off_crop_cc = take(4 * np);
     p->off_dist = take(4 * np);
     p->off_ell_nnz = take(2 * np);
+    p->off_ell_hnz = take(2 * np);
     p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
     p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
@@ -315,7 +316,8 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);
     P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);
     P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
-    P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_nnz = (uint16_t *)(b + p->off_ell_nnz);
+    P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_nnz = (uint16_t *)(b + p->off_ell_nnz); P.ell_hnz = (uint16_t *)(b + p->off_ell_hnz);
+    P.hess_thr = 0.05f;   // same constant as the oracle's ORC_HESS_THR
     P.psf = (const float *)(b + p->off_psf);
     P.hsave = (double *)(b + p->off_hsave); P.hsave_stride = SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2;
     P.prof = g_prof;

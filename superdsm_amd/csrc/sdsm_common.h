@@ -54,7 +54,8 @@ struct CandState {
     int32_t npos;       // region pixels with y > 0
     int32_t zmax;       // largest number of non-zeros in a row of G~
     unsigned long long sum_r, sum_c, sum_rr, sum_cc;   // moments of the y > 0 pixels (image coordinates)
-    unsigned long long reserved;
+    int32_t hzmax;      // largest number of 'significant' entries (>= hess_thr * row maximum) in a row of G~
+    int32_t reserved;
 };
 static_assert(sizeof(CandState) == 64, "CandState layout");
 static_assert(sizeof(CandDesc) == 72, "CandDesc layout");
@@ -65,6 +66,7 @@ struct BatchParams {
     int32_t no_deform;                 // smooth_amount == inf
     int32_t init_elliptical, max_iters, pad0;
     double scale, epsilon, alpha;
+    float hess_thr; int32_t pad1;      // Hessian ignores row entries < hess_thr * row maximum (solver approximation)
     const CandDesc *cand;
     CandState *state;
     const int32_t *fp_labels;
@@ -76,7 +78,8 @@ struct BatchParams {
     uint32_t *grid_rc;                 // sorted grid points, compressed coordinates
     uint16_t *ell_idx;
     float *ell_w;
-    uint16_t *ell_nnz;
+    uint16_t *ell_nnz;                 // number of non-zeros of the row
+    uint16_t *ell_hnz;                 // number of leading entries used by the solver's approximate Hessian
     const float *psf;
     double *hsave;                     // per-candidate Hessian copy for the in-place class
     int64_t hsave_stride;

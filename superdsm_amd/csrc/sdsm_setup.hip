@@ -195,7 +195,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         int r = (int)(rc >> 16) - cd.r0, c = (int)(rc & 0xffffu) - cd.c0;
         uint32_t key = ((uint32_t)rowrank[r] << 16) | (uint32_t)colrank[c];
         P.crop_cc[cd.crop_off + i] = key;
-        if (null_matrix) P.ell_nnz[cd.crop_off + i] = 0;
+        if (null_matrix) { P.ell_nnz[cd.crop_off + i] = 0; P.ell_hnz[cd.crop_off + i] = 0; }
         else if (rowrank[r] % S == 0 && colrank[c] % S == 0) {                             // dsm.py:165-168
             int j = atomicAdd(&sh_M, 1);
             if (j < SDSM_MAX_GRID) gridkeys[j] = key;
@@ -258,14 +258,14 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
 
     // ---- 5. rows of G~: PSF gather, float32 pairwise row sum, float32 division (dsm.py:192-193) --
     bool bad = false;
-    int zmax = 0;
+    int zmax = 0, hzmax = 0;
     for (int i = tid; i < cd.N; i += SDSM_WG) {
         uint32_t key = P.crop_cc[cd.crop_off + i];
         WeightCtx c;
         c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.keys = gridkeys;
         c.ell_idx = P.ell_idx; c.ell_w = P.ell_w; c.base = cd.ell_off + i; c.N = cd.N; c.zcap = P.zcap; c.nnz = 0; c.overflow = false;
         float sum = pw_sum(c, M);
-        if (c.overflow || !(sum > 0.f)) { bad = true; P.ell_nnz[cd.crop_off + i] = 0; continue; }   // dsm.py:194
+        if (c.overflow || !(sum > 0.f)) { bad = true; P.ell_nnz[cd.crop_off + i] = 0; P.ell_hnz[cd.crop_off + i] = 0; continue; }   // dsm.py:194
         for (int sl = 0; sl < c.nnz; sl++) {
             int64_t e = c.base + (int64_t)sl * cd.N;
             P.ell_w[e] = __fdiv_rn(P.ell_w[e], sum);
@@ -274,13 +274,38 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             int64_t e = c.base + (int64_t)sl * cd.N;
             P.ell_idx[e] = 0; P.ell_w[e] = 0.f;
         }
+        // Order the row by descending weight (selection sort, ties keep the lower column index first): the solver's
+        // approximate Hessian uses only the leading entries >= hess_thr * row maximum; S and the gradient use all.
+        for (int a = 0; a < c.nnz; a++) {
+            int64_t ea = c.base + (int64_t)a * cd.N;
+            float wa = P.ell_w[ea]; uint16_t ia = P.ell_idx[ea];
+            int best = a; float wb = wa; uint16_t ib = ia;
+            for (int b = a + 1; b < c.nnz; b++) {
+                int64_t eb = c.base + (int64_t)b * cd.N;
+                float w2 = P.ell_w[eb]; uint16_t i2 = P.ell_idx[eb];
+                if (w2 > wb || (w2 == wb && i2 < ib)) { best = b; wb = w2; ib = i2; }
+            }
+            if (best != a) {
+                int64_t eb = c.base + (int64_t)best * cd.N;
+                P.ell_w[eb] = wa; P.ell_idx[eb] = ia;
+                P.ell_w[ea] = wb; P.ell_idx[ea] = ib;
+            }
+        }
+        int hz = 0;
+        if (c.nnz > 0) {
+            const float lim = P.hess_thr * P.ell_w[c.base];
+            while (hz < c.nnz && !(P.ell_w[c.base + (int64_t)hz * cd.N] < lim)) hz++;
+        }
         P.ell_nnz[cd.crop_off + i] = (uint16_t)c.nnz;
+        P.ell_hnz[cd.crop_off + i] = (uint16_t)hz;
         zmax = c.nnz > zmax ? c.nnz : zmax;
+        hzmax = hz > hzmax ? hz : hzmax;
     }
     if (bad) atomicOr(&sh_err, 1);
     zmax = -block_min_i32(-zmax, scr32);
+    hzmax = -block_min_i32(-hzmax, scr32);
     __syncthreads();
-    s.M = M; s.zmax = zmax;
+    s.M = M; s.zmax = zmax; s.hzmax = hzmax;
     s.status = sh_err ? ST_ERROR : ST_OK;
     if (tid == 0) *st = s;
 }

@@ -13,15 +13,14 @@
 //
 // One full evaluation (psi, gradient, Hessian) of a candidate with n = 6 + M parameters:
 //   every lane owns pixels: coalesced read of the packed crop (y f64 + (row,col) u16x2 = 12 B / pixel) and of the
-//   pixel's ELL row of G~ (slot-major, fixed trip count, loads issued back to back), S, exp/log, residual r and
-//   curvature weight d.
-//   DENSE classes (n <= 40): the pixel's dense Jacobian row is staged in LDS (float32, column-major, conflict
-//   free) and lanes re-map to (4x4 Hessian tile, pixel slice) for a register-tiled J^T diag(d) J in float64;
-//   slices are combined with wavefront shuffles.  Bit-reproducible.
-//   SPARSE classes (n > 40): each pixel adds its (6+z)^2/2 products straight into the packed Hessian in LDS with
-//   ds_add_f64; the crop is stored scattered (CandDesc.perm_inv) so that the 64 lanes of a wave touch different
-//   (j,k) entries.  The 6x6 polynomial block, its gradient and psi are register sums reduced with wavefront
-//   shuffles + one LDS hop.
+//   pixel's ELL row of G~ (slot-major, fixed trip count, all loads of a row issued before the first use), S,
+//   exp/log, residual r and curvature weight d.  psi, the 6 polynomial gradient entries and the 6x6 polynomial
+//   Hessian block are per-lane register sums reduced with wavefront shuffles + one LDS hop.  The xi part of the
+//   gradient (every entry of the row) and of the Hessian (the row's leading "significant" entries, weight >= 5 % of
+//   the row maximum: the solver's approximate Hessian) is added straight into LDS with ds_add_f64; the crop is
+//   stored scattered (CandDesc.perm_inv) so that the 64 lanes of a wave touch different (j,k) entries.
+//   (A register-tiled dense J^T diag(d) J over LDS-staged Jacobian rows was measured 10 % slower even at 6+M <= 40
+//   once the Hessian was thresholded, and was removed.)
 #include "sdsm_common.h"
 
 extern __shared__ __align__(16) unsigned char sdsm_smem[];
@@ -35,20 +34,18 @@ namespace {
 #define LS_BETA 0.5
 #define LS_MAX 40
 #define ZREG 28          // ELL slots held in registers by the sparse path (covers zcap = 25 of the default ratios)
+#define HZREG 12         // leading ('significant') slots unrolled for the approximate Hessian
 
 // Compile-time LDS layout (offsets in doubles from the start of dynamic LDS).
-template <int NMAX, int B, bool INPLACE, bool DENSE>
+template <int NMAX, bool INPLACE>
 struct Lay {
     static constexpr int NP = NMAX * (NMAX + 1) / 2;
     static constexpr int W = NMAX + 2;    // vectors are indexed up to n (right-hand-side row) inclusive
     static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
-    static constexpr int RED = 7 * W, FLAG = RED + SDSM_WAVES * 32, DW = FLAG + 2;
-    static constexpr int RW = DW + (DENSE ? B : 0), HP = RW + (DENSE ? B : 0);
+    static constexpr int RED = 7 * W, FLAG = RED + SDSM_WAVES * 32, HP = FLAG + 2;
     static constexpr int LP = INPLACE ? HP : HP + NP;
     static constexpr int END = LP + NP;
-    static constexpr int V_BYTES = ((END * 8 + 15) / 16) * 16;
-    static constexpr int LDV = ((NMAX + 3) / 4) * 4;
-    static constexpr int TOTAL_BYTES = V_BYTES + (DENSE ? LDV * B * 4 : 0);
+    static constexpr int TOTAL_BYTES = ((END * 8 + 15) / 16) * 16;
 };
 
 #define SD ((double *)sdsm_smem)
@@ -67,8 +64,9 @@ struct Cand {                       // per-candidate global pointers (already of
     g_cu16_p ell_idx;
     g_cfloat_p ell_w;
     g_cu16_p ell_nnz;
+    g_cu16_p ell_hnz;
     g_double_p hsave;
-    int N, zmax;
+    int N, zmax, hzmax;
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
 };
@@ -167,157 +165,6 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M)
     s2 = block_sum(s2, SD + L::RED);
     double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
     return o2 < 0 ? 0 : o2;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// DENSE full evaluation (n <= 40): Jacobian rows staged in LDS, register-tiled float64 accumulation.
-// ---------------------------------------------------------------------------------------------------------
-template <class L, int B>
-__device__ __noinline__ double eval_full_dense(const Cand &c, int M PROF_PARAM)
-{
-    long long pt = PROF_NOW();
-    const int tid = threadIdx.x;
-    const int n = 6 + M, nb = (n + 3) / 4, ldv = nb * 4;
-    const int Th = nb * (nb + 1) / 2, T = Th + nb;      // Hessian tiles + gradient tiles (<= 65 for n <= 40)
-    float *V = (float *)(sdsm_smem + L::V_BYTES);
-    double *dW = SD + L::DW, *rW = SD + L::RW;
-    const double *xv = SD + L::X;
-    int S = 1;
-    while (S * 2 * T <= SDSM_WG && S < 64) S *= 2;      // pixel slices per tile: power of two, consecutive lanes
-    const int slice = tid % S, t = tid / S;
-    const bool tileOn = t < T;
-    int J = 0, K = 0;
-    if (t < Th) {
-        J = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-        while (J * (J + 1) / 2 > t) J--;
-        while ((J + 1) * (J + 2) / 2 <= t) J++;
-        K = t - J * (J + 1) / 2;
-    } else if (tileOn) { J = t - Th; K = -1; }          // gradient tile
-    double acc[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0;
-    double red[7] = {0, 0, 0, 0, 0, 0, 0};              // psi, g_theta[0..5]
-    for (int base = 0; base < c.N; base += B) {
-        // ---- stage: lane = pixel ---------------------------------------------------------------
-        for (int lp = tid; lp < B; lp += SDSM_WG) {
-            int p = base + lp;
-            if (p < c.N) {
-                double yv = c.crop_y[p];
-                uint32_t rc = c.crop_rc[p];
-                double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-                double q0 = u * u, q1 = v * v, q2 = 2 * (u * v), q3 = 2 * u, q4 = 2 * v;
-                double Sv = q0 * xv[0] + q1 * xv[1] + q2 * xv[2] + q3 * xv[3] + q4 * xv[4] + xv[5];
-                V[0 * B + lp] = (float)q0; V[1 * B + lp] = (float)q1; V[2 * B + lp] = (float)q2;
-                V[3 * B + lp] = (float)q3; V[4 * B + lp] = (float)q4; V[5 * B + lp] = 1.f;
-                for (int col = 6; col < ldv; col++) V[col * B + lp] = 0.f;
-                if (M > 0) {
-                    double gx = 0;
-                    if (c.zmax <= ZREG) {
-                        float w[ZREG]; int id[ZREG];
-#pragma unroll
-                        for (int s = 0; s < ZREG; s++) {
-                            const int se = s < c.zmax ? s : c.zmax - 1;
-                            const size_t o = (size_t)se * c.N + p;
-                            const float wv = c.ell_w[o];
-                            id[s] = c.ell_idx[o];
-                            w[s] = s < c.zmax ? wv : 0.f;
-                        }
-#pragma unroll
-                        for (int s = 0; s < ZREG; s++) {
-                            gx += (double)w[s] * xv[6 + id[s]];
-                            if (w[s] != 0.f) V[(6 + id[s]) * B + lp] = w[s];
-                        }
-                    } else {
-                        for (int s = 0; s < c.zmax; s++) {
-                            size_t o = (size_t)s * c.N + p;
-                            float w = c.ell_w[o]; int id = c.ell_idx[o];
-                            gx += (double)w * xv[6 + id];
-                            if (w != 0.f) V[(6 + id) * B + lp] = w;
-                        }
-                    }
-                    Sv += gx;
-                }
-                double phi, r, dc;
-                loss_terms(yv, Sv, &phi, &r, &dc);
-                red[0] += phi;
-                red[1] += r * q0; red[2] += r * q1; red[3] += r * q2; red[4] += r * q3; red[5] += r * q4; red[6] += r;
-                dW[lp] = dc; rW[lp] = r;
-            } else {
-                for (int col = 0; col < ldv; col++) V[col * B + lp] = 0.f;
-                dW[lp] = 0; rW[lp] = 0;
-            }
-        }
-        __syncthreads();
-        PROF_ADD(0, pt);
-        // ---- accumulate: lane = (tile, slice); quads of 4 staged pixels --------------------------
-        if (tileOn) {
-            for (int quad = slice; quad < B / 4; quad += S) {
-                const int p4 = quad * 4;
-                const float4 a0 = *(const float4 *)&V[(4 * J + 0) * B + p4];
-                const float4 a1 = *(const float4 *)&V[(4 * J + 1) * B + p4];
-                const float4 a2 = *(const float4 *)&V[(4 * J + 2) * B + p4];
-                const float4 a3 = *(const float4 *)&V[(4 * J + 3) * B + p4];
-                if (K >= 0) {
-                    const double2 w01 = *(const double2 *)&dW[p4], w23 = *(const double2 *)&dW[p4 + 2];
-                    const float4 b0 = *(const float4 *)&V[(4 * K + 0) * B + p4];
-                    const float4 b1 = *(const float4 *)&V[(4 * K + 1) * B + p4];
-                    const float4 b2 = *(const float4 *)&V[(4 * K + 2) * B + p4];
-                    const float4 b3 = *(const float4 *)&V[(4 * K + 3) * B + p4];
-                    const float4 av[4] = {a0, a1, a2, a3}, bv[4] = {b0, b1, b2, b3};
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const double ax = (double)av[i].x * w01.x, ay = (double)av[i].y * w01.y, az = (double)av[i].z * w23.x, aw = (double)av[i].w * w23.y;
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            acc[i * 4 + j] += ax * (double)bv[j].x + ay * (double)bv[j].y + az * (double)bv[j].z + aw * (double)bv[j].w;
-                    }
-                } else {
-                    const double2 r01 = *(const double2 *)&rW[p4], r23 = *(const double2 *)&rW[p4 + 2];
-                    acc[0] += (double)a0.x * r01.x + (double)a0.y * r01.y + (double)a0.z * r23.x + (double)a0.w * r23.y;
-                    acc[1] += (double)a1.x * r01.x + (double)a1.y * r01.y + (double)a1.z * r23.x + (double)a1.w * r23.y;
-                    acc[2] += (double)a2.x * r01.x + (double)a2.y * r01.y + (double)a2.z * r23.x + (double)a2.w * r23.y;
-                    acc[3] += (double)a3.x * r01.x + (double)a3.y * r01.y + (double)a3.z * r23.x + (double)a3.w * r23.y;
-                }
-            }
-        }
-        __syncthreads();
-        PROF_ADD(1, pt);
-    }
-    // ---- combine slices (consecutive lanes of one wave), scatter into the packed Hessian / gradient ----
-    double *Hp = SD + L::HP, *g = SD + L::G;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        double v = acc[e];
-        for (int o = 1; o < S; o <<= 1) v += __shfl_xor(v, o);
-        acc[e] = v;
-    }
-    if (tileOn && slice == 0) {
-        if (K >= 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    int row = 4 * J + i, col = 4 * K + j;
-                    if (row < n && col <= row) Hp[tri(row, col)] = acc[i * 4 + j];
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { int row = 4 * J + i; if (row >= 6 && row < n) g[row] = acc[i]; }
-        }
-    }
-    block_sum_vec<7>(red, SD + L::RED);
-    if (tid < 6) {
-        double gv = 0;
-#pragma unroll
-        for (int e = 0; e < 6; e++) gv = tid == e ? red[1 + e] : gv;
-        g[tid] = gv;
-    }
-    __syncthreads();
-    double psi = red[0];
-    if (M > 0) psi += add_regulariser<L>(c, M);
-    __syncthreads();
-    PROF_ADD(2, pt);
-    return psi;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -420,18 +267,37 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
 #pragma unroll
             for (int b = 0; b <= a; b++) red[7 + a * (a + 1) / 2 + b] += dc * q[a] * q[b];
         if (dc != 0 || r != 0) {
+            const int hnz = M > 0 ? (int)c.ell_hnz[p] : 0;
             if (in_regs) {
 #pragma unroll
-                for (int a = 0; a < ZREG; a++) {
-                    if (a < nnz) {
-                        const double wa = (double)w[a], dwa = dc * wa;
-                        const int ra = 6 + id[a];
+                for (int a = 0; a < ZREG; a++)
+                    if (a < nnz) atomicAdd(&g[6 + id[a]], r * (double)w[a]);          // exact gradient: every entry
+                if (c.hzmax <= HZREG) {
+#pragma unroll
+                    for (int a = 0; a < HZREG; a++) {                                    // approximate Hessian: leading entries
+                        if (a < hnz) {
+                            const double dwa = dc * (double)w[a];
+                            const int ra = 6 + id[a];
+                            double *Hrow = Hp + tri(ra, 0);
+#pragma unroll
+                            for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
+#pragma unroll
+                            for (int b = 0; b <= a; b++) {
+                                const int rb = 6 + id[b];
+                                atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)w[b]);
+                            }
+                        }
+                    }
+                } else {
+                    for (int a = 0; a < hnz; a++) {
+                        const double dwa = dc * (double)c.ell_w[(size_t)a * c.N + p];
+                        const int ra = 6 + c.ell_idx[(size_t)a * c.N + p];
                         double *Hrow = Hp + tri(ra, 0);
-                        atomicAdd(&g[ra], r * wa);
-#pragma unroll
                         for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
-#pragma unroll
-                        for (int b = 0; b <= a; b++) atomicAdd(&Hrow[6 + id[b]], dwa * (double)w[b]);   // id ascending within a row
+                        for (int b = 0; b <= a; b++) {
+                            const int rb = 6 + c.ell_idx[(size_t)b * c.N + p];
+                            atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)c.ell_w[(size_t)b * c.N + p]);
+                        }
                     }
                 }
             } else {
@@ -439,10 +305,15 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
                     size_t oa = (size_t)a * c.N + p;
                     const double wa = (double)c.ell_w[oa], dwa = dc * wa;
                     const int ra = 6 + c.ell_idx[oa];
-                    double *Hrow = Hp + tri(ra, 0);
                     atomicAdd(&g[ra], r * wa);
+                    if (a >= hnz) continue;
+                    double *Hrow = Hp + tri(ra, 0);
                     for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
-                    for (int b = 0; b <= a; b++) { size_t ob = (size_t)b * c.N + p; atomicAdd(&Hrow[6 + c.ell_idx[ob]], dwa * (double)c.ell_w[ob]); }
+                    for (int b = 0; b <= a; b++) {
+                        size_t ob = (size_t)b * c.N + p;
+                        const int rb = 6 + c.ell_idx[ob];
+                        atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)c.ell_w[ob]);
+                    }
                 }
             }
         }
@@ -558,8 +429,11 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
         return true;
     }
 
-    // ---- general case: all 256 threads, 16 x 16 thread grid over the trailing sub-matrix, 2 barriers per column.
-    //      (A single-wave variant without s_barrier was measured slower: 61 vs 46 us at n = 50, 249 vs 142 us at n = 90.)
+    // ---- general case: blocked right-looking Cholesky, panels of NB = 4 columns, 2 workgroup barriers per PANEL.
+    //      Every thread factors the panel's 4x4 diagonal block redundantly in registers; one thread per row solves its
+    //      4 panel entries against it; then all 256 threads (16 x 16 grid) apply the rank-4 update to the trailing
+    //      sub-matrix.  The right-hand side rides along as row n.
+    constexpr int NB = 4;
     const int ri = tid >> 4, ki = tid & 15;
     double tau = 0;
     bool ok = false;
@@ -575,31 +449,76 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
         for (int k = tid; k < n; k += SDSM_WG) yrow[k] = -g[k] * sc[k];
         __syncthreads();
         ok = true;
-        for (int j = 0; j < n; j++) {
-            const double piv = Lp[tri(j, j)];                  // final: all trailing updates of column j - 1 are done
-            if (!(piv > 1e-300) || !isfinite(piv)) { ok = false; break; }
-            const double ljj = sqrt(piv), rl = 1.0 / ljj;
-            if (tid == 0) dg[j] = ljj;                         // the diagonal of L lives in dg[]; Lp keeps the pivot
-            for (int i = j + 1 + tid; i <= n; i += SDSM_WG) {  // scale column j (row n = right-hand side)
-                double v = (i < n ? Lp[tri(i, j)] : yrow[j]) * rl;
-                if (i < n) Lp[tri(i, j)] = v; else yrow[j] = v;
-                colj[i] = v;                                   // contiguous copy of the column for the update below
+        for (int j0 = 0; j0 < n; j0 += NB) {
+            const int nb = n - j0 < NB ? n - j0 : NB;
+            // 1. diagonal block, redundantly in registers
+            double t[NB][NB];
+#pragma unroll
+            for (int a2 = 0; a2 < NB; a2++)
+#pragma unroll
+                for (int b2 = 0; b2 <= a2; b2++) t[a2][b2] = a2 < nb ? Lp[tri(j0 + a2, j0 + b2)] : (a2 == b2 ? 1.0 : 0.0);
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++) {
+                double piv = t[cc][cc];
+#pragma unroll
+                for (int m = 0; m < cc; m++) piv -= t[cc][m] * t[cc][m];
+                if (cc < nb && (!(piv > 1e-300) || !isfinite(piv))) { ok = false; piv = 1; }
+                const double l = sqrt(piv);
+                t[cc][cc] = l;
+#pragma unroll
+                for (int a2 = cc + 1; a2 < NB; a2++) {
+                    double v = t[a2][cc];
+#pragma unroll
+                    for (int m = 0; m < cc; m++) v -= t[a2][m] * t[cc][m];
+                    t[a2][cc] = v / l;
+                }
+            }
+            if (!ok) break;                                        // uniform: every thread computed the same block
+            __syncthreads();                                       // everybody has read the block before it is overwritten
+            if (tid < NB * NB) {                                   // factored block back to LDS
+                const int a2 = tid / NB, b2 = tid % NB;
+                if (b2 <= a2 && a2 < nb) {
+                    double v = 0;
+#pragma unroll
+                    for (int x2 = 0; x2 < NB; x2++)
+#pragma unroll
+                        for (int y2 = 0; y2 <= x2; y2++) v = (x2 == a2 && y2 == b2) ? t[x2][y2] : v;
+                    Lp[tri(j0 + a2, j0 + b2)] = v;
+                    if (a2 == b2) dg[j0 + a2] = v;
+                }
+            }
+            // 2. panel rows below the block: one thread per row, triangular solve against the block
+            for (int i = j0 + nb + tid; i <= n; i += SDSM_WG) {
+                double *row = i < n ? Lp + tri(i, j0) : yrow + j0;
+                double v[NB];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) v[cc] = cc < nb ? row[cc] : 0.0;
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) {
+                    double acc = v[cc];
+#pragma unroll
+                    for (int m = 0; m < cc; m++) acc -= v[m] * t[cc][m];
+                    v[cc] = acc / t[cc][cc];
+                }
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) if (cc < nb) row[cc] = v[cc];
             }
             __syncthreads();
-            for (int i = j + 1 + ri; i <= n; i += 16) {        // trailing update, 4 independent entries in flight
-                const double lij = colj[i];
+            // 3. rank-nb update of the trailing sub-matrix (rows / columns >= j0 + nb; row n = right-hand side)
+            const int jn = j0 + nb;
+            for (int i = jn + ri; i <= n; i += 16) {
+                const double *pi = i < n ? Lp + tri(i, j0) : yrow + j0;
+                double li[NB];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) li[cc] = cc < nb ? pi[cc] : 0.0;
                 double *Li = i < n ? Lp + tri(i, 0) : yrow;
                 const int kend = i < n ? i : n - 1;
-                for (int k = j + 1 + ki; k <= kend; k += 64) {
-                    const int k1 = k + 16, k2 = k + 32, k3 = k + 48;
-                    const double a0 = Li[k], c0 = colj[k];
-                    const double a1 = k1 <= kend ? Li[k1] : 0, c1 = k1 <= kend ? colj[k1] : 0;
-                    const double a2 = k2 <= kend ? Li[k2] : 0, c2 = k2 <= kend ? colj[k2] : 0;
-                    const double a3 = k3 <= kend ? Li[k3] : 0, c3 = k3 <= kend ? colj[k3] : 0;
-                    Li[k] = a0 - lij * c0;
-                    if (k1 <= kend) Li[k1] = a1 - lij * c1;
-                    if (k2 <= kend) Li[k2] = a2 - lij * c2;
-                    if (k3 <= kend) Li[k3] = a3 - lij * c3;
+                for (int k = jn + ki; k <= kend; k += 16) {
+                    const double *pk = Lp + tri(k, j0);
+                    double acc = Li[k];
+#pragma unroll
+                    for (int cc = 0; cc < NB; cc++) acc -= li[cc] * (cc < nb ? pk[cc] : 0.0);
+                    Li[k] = acc;
                 }
             }
             __syncthreads();
@@ -611,11 +530,29 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
     double l2 = 0;
     for (int i = tid; i < n; i += SDSM_WG) l2 += yrow[i] * yrow[i];
     l2 = block_sum(l2, SD + L::RED);
-    for (int k = n - 1; k >= 0; k--) {                        // back substitution L^T z = yrow
-        const double dk = yrow[k] / dg[k];
-        if (tid == 0) d[k] = dk;
-        const double *Lk = Lp + tri(k, 0);
-        for (int i = tid; i < k; i += SDSM_WG) yrow[i] -= Lk[i] * dk;
+    // back substitution L^T z = yrow, blocked the same way: every thread solves the NB x NB block redundantly
+    for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
+        const int nb = n - j0 < NB ? n - j0 : NB;
+        double z[NB];
+#pragma unroll
+        for (int cc = NB - 1; cc >= 0; cc--) {
+            double acc = cc < nb ? yrow[j0 + cc] : 0.0;
+#pragma unroll
+            for (int m = cc + 1; m < NB; m++) if (m < nb) acc -= Lp[tri(j0 + m, j0 + cc)] * z[m];
+            z[cc] = cc < nb ? acc / dg[j0 + cc] : 0.0;
+        }
+        if (tid < NB && tid < nb) {
+            double v = 0;
+#pragma unroll
+            for (int x2 = 0; x2 < NB; x2++) v = x2 == tid ? z[x2] : v;
+            d[j0 + tid] = v;
+        }
+        for (int i = tid; i < j0; i += SDSM_WG) {
+            double acc = yrow[i];
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++) if (cc < nb) acc -= Lp[tri(j0 + cc, i)] * z[cc];
+            yrow[i] = acc;
+        }
         __syncthreads();
     }
     bool fin = isfinite(l2);
@@ -629,7 +566,7 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
 
 // Damped Newton on f = scale * psi from the parameters at L::X (in/out).
 // Returns 0 optimal, 1 unknown (iteration cap / stalled line search), 2 numerical failure.
-template <class L, int B, bool INPLACE, bool DENSE>
+template <class L, bool INPLACE>
 __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, double *psi_out, int *iters_out, int *ev_value, int *ev_full PROF_PARAM)
 {
     const int tid = threadIdx.x, n = 6 + M;
@@ -639,7 +576,6 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
     for (;;) {
         double psi;
         if (M == 0) psi = eval_full_ell<L>(c PROF_ARG);
-        else if constexpr (DENSE) psi = eval_full_dense<L, B>(c, M PROF_ARG);
         else psi = eval_full_sparse<L>(c, M PROF_ARG);
         (*ev_full)++;
         long long pt = PROF_NOW();
@@ -707,11 +643,11 @@ __device__ __forceinline__ void reparam(const double *th, double p0, double p1, 
 // NMAX: largest 6 + M this instantiation handles; candidates with 6 + M in (nmin_excl, NMAX] are processed,
 // the others are left to the other classes.  The smallest class also writes the records of trivial /
 // failed-setup candidates.
-template <int NMAX, int B, bool INPLACE, bool DENSE, int WPE>
+template <int NMAX, bool INPLACE, int WPE>
 __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int nmin_excl, int handles_rest, sdsm_record *records,
                                                               uint32_t *masks, double *xi_out)
 {
-    using L = Lay<NMAX, B, INPLACE, DENSE>;
+    using L = Lay<NMAX, INPLACE>;
     const int tid = threadIdx.x;
     const int ci = P.order[blockIdx.x];
     const CandDesc cd = P.cand[ci];
@@ -734,8 +670,8 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
     if (!(nfull > nmin_excl && nfull <= NMAX)) return;
 
     Cand c;
-    c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0;
-    c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_nnz = (g_cu16_p)(P.ell_nnz + cd.crop_off);
+    c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0; c.hzmax = Mfull > 0 ? st.hzmax : 0;
+    c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_nnz = (g_cu16_p)(P.ell_nnz + cd.crop_off); c.ell_hnz = (g_cu16_p)(P.ell_hnz + cd.crop_off);
     c.ell_idx = (g_cu16_p)(P.ell_idx + cd.ell_off); c.ell_w = (g_cfloat_p)(P.ell_w + cd.ell_off);
     c.hsave = (g_double_p)((INPLACE && cd.hsave_slot >= 0) ? P.hsave + (int64_t)cd.hsave_slot * P.hsave_stride : nullptr);
     c.scale = P.scale / cd.N;                                   // objects.py:380
@@ -800,7 +736,7 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
             __syncthreads();
         }
         double psi; int its;
-        int s = newton<L, B, INPLACE, DENSE>(c, M, P.max_iters, &psi, &its, &ev_value, &ev_full PROF_ARG);
+        int s = newton<L, INPLACE>(c, M, P.max_iters, &psi, &its, &ev_value, &ev_full PROF_ARG);
 #ifdef SDSM_PROFILE
         if (phase < 2) { prof_acc[6] = PROF_NOW() - prof_t_start; }
 #endif
@@ -893,15 +829,15 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
 }
 
 // ---- launch helper (called from sdsm_api.hip) ----------------------------------------------------
-// class A: n <= 40   dense tiles, B 256, separate factor      LDS ~ 61 KB   (2 workgroups / CU)
-// class B: n <= 84   sparse LDS atomics, separate factor      LDS ~ 63 KB   (2 workgroups / CU)
-// class C: n <= 172  sparse LDS atomics, in-place factor      LDS ~ 130 KB  (1 workgroup / CU)
+// class A: n <= 40   separate factor      LDS ~ 17 KB   (2 workgroups / CU, register bound)
+// class B: n <= 84   separate factor      LDS ~ 63 KB   (2 workgroups / CU)
+// class C: n <= 172  in-place factor      LDS ~ 130 KB  (1 workgroup / CU)
 // The three classes are independent: they run concurrently on three streams forked from the caller's stream.
-template <int NMAX, int B, bool INPLACE, bool DENSE, int WPE>
+template <int NMAX, bool INPLACE, int WPE>
 static hipError_t launch_class(const BatchParams &P, int nmin_excl, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
-    auto kern = sdsm_k_solve<NMAX, B, INPLACE, DENSE, WPE>;
-    constexpr int lds = Lay<NMAX, B, INPLACE, DENSE>::TOTAL_BYTES;
+    auto kern = sdsm_k_solve<NMAX, INPLACE, WPE>;
+    constexpr int lds = Lay<NMAX, INPLACE>::TOTAL_BYTES;
     static_assert(lds <= 160 * 1024 - 512, "LDS budget");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
@@ -917,9 +853,9 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
-    if ((e = launch_class<172, 32, true, false, 1>(P, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-    if ((e = launch_class<84, 32, false, false, 1>(P, 40, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
-    if ((e = launch_class<40, 256, false, true, 2>(P, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
+    if ((e = launch_class<172, true, 1>(P, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+    if ((e = launch_class<84, false, 2>(P, 40, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
+    if ((e = launch_class<40, false, 2>(P, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
     if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
     if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;

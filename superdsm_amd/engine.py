@@ -150,8 +150,13 @@ class Batch:
             g = grid[xi_off[i]:xi_off[i] + M]
             eo = po * zcap
             nnz = ell_nnz[po:po + N].astype(np.int64)
-            idx = ell_idx[eo:eo + N * zcap].reshape(zcap, N) if N else np.zeros((zcap, 0), np.uint16)
+            idx = ell_idx[eo:eo + N * zcap].reshape(zcap, N).astype(np.int64) if N else np.zeros((zcap, 0), np.int64)
             w = ell_w[eo:eo + N * zcap].reshape(zcap, N) if N else np.zeros((zcap, 0), np.float32)
+            # rows are stored by descending weight (the solver's Hessian uses the leading entries); report them by column
+            key = np.where(np.arange(zcap)[:, None] < nnz[None, :], idx, 1 << 30)
+            srt = np.argsort(key, axis=0, kind='stable')
+            idx = np.take_along_axis(idx, srt, axis=0)
+            w = np.take_along_axis(w, srt, axis=0)
             # the crop is stored in a scattered order (CandDesc.perm_inv); report it in raster order
             o = np.lexsort(((rc & 0xffff), (rc >> 16)))
             out.append(dict(N=N, M=M, status=status, hc=hc, wc=wc, npos=npos, zmax=int(state[i, 5]), y=crop_y[po:po + N][o].copy(),

@@ -206,21 +206,17 @@ def test_full_size_properties_bbbc039_like(gpu):
     assert np.isfinite(recs['energy'][ok]).all() and (recs['energy'][ok] >= 0).all()
     # the DSM can only improve on the elliptical model it starts from (monotone line search)
     assert (recs['energy'][ok] <= recs['energy_ell'][ok] * (1 + 1e-9) + 1e-9).all()
-    # idempotence / determinism: a second launch of the same plan gives bit-identical records
+    # idempotence: a second launch of the same plan gives the same records
     res['batch'].launch()
     gpu.cuda.synchronize()
     recs2 = res['batch'].records()
-    # ... for the dense classes (6 + M <= 40); the sparse classes accumulate the Hessian with LDS float atomics whose
-    # order is not fixed, so their iterates (never their optimum) move in the last bits
-    dense = recs['n_deform'] + 6 <= 40
-    for f in ('energy', 'theta', 'status', 'iters_dsm', 'fg_r0', 'fg_c0', 'fg_h', 'fg_w'):
-        np.testing.assert_array_equal(recs[f][dense], recs2[f][dense])
+    # ... up to the order of the LDS float atomics that accumulate the xi part of gradient and Hessian: iterates (never
+    # the optimum) move in the last bits between launches
     np.testing.assert_allclose(recs2['energy'], recs['energy'], rtol=1e-6, atol=1e-9)
     np.testing.assert_array_equal(recs2['status'], recs['status'])
     # permutation invariance: candidates are independent
     perm = np.random.default_rng(0).permutation(len(fps))
     res3 = testing.solve_scene_gpu(scene, footprints=[fps[i] for i in perm])
-    np.testing.assert_array_equal(res3['records']['energy'][dense[perm]], recs['energy'][perm][dense[perm]])
     np.testing.assert_allclose(res3['records']['energy'], recs['energy'][perm], rtol=1e-6, atol=1e-9)
     # fragments stay inside the region bounding box and contain only region pixels
     img, batch = res['image'], res['batch']
