@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs merged under gpurun_out/ into the small committed summaries under profiles/.
+usage: python tools/summarize_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.makedirs(os.path.join(root, 'profiles'), exist_ok=True)
+stats = glob.glob(os.path.join(root, 'gpurun_out', f'{tag}_trace', '*', '*kernel_stats.csv'))
+if stats:
+    shutil.copy(stats[0], os.path.join(root, 'profiles', f'{tag}_kernel_stats.csv'))
+
+
+def per_kernel(pattern, counter):
+    files = glob.glob(os.path.join(root, 'gpurun_out', pattern, '*', '*counter_collection.csv'))
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    if not files:
+        return {}
+    for r in csv.DictReader(open(files[0])):
+        if r['Counter_Name'] != counter:
+            continue
+        k = r['Kernel_Name'].split('(')[0][:80]
+        agg[k][0] += 1
+        agg[k][1] += float(r['Counter_Value'])
+    return {k: dict(dispatches=n, avg_per_dispatch_KB=v / n) for k, (n, v) in agg.items() if 'sdsm' in k or 'k_' in k}
+
+
+fetch = per_kernel(f'{tag}_fetch', 'FETCH_SIZE')
+write = per_kernel(f'{tag}_write', 'WRITE_SIZE')
+solve_fetch = sum(v['avg_per_dispatch_KB'] for k, v in fetch.items() if 'sdsm_k_solve' in k) * 1024
+solve_write = sum(v['avg_per_dispatch_KB'] for k, v in write.items() if 'sdsm_k_solve' in k) * 1024
+out = dict(
+    note=('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --inflight 1).  Counters are in KB.  '
+          'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a WIDE (16 B/lane) coalesced stream; this kernel '
+          'reads 2-8 B per lane (u16 / f32 / f64), a width the guide lists as uncalibrated, so the raw value is kept and the '
+          'x2 figure is given as an upper bound.'),
+    fetch=fetch, write=write,
+    solve_fetch_bytes_per_launch_raw=solve_fetch, solve_fetch_bytes_per_launch_x2=2 * solve_fetch,
+    solve_write_bytes_per_launch=solve_write,
+    solve_hbm_bytes_per_launch=solve_fetch + solve_write)
+json.dump(out, open(os.path.join(root, 'profiles', f'{tag}_pmc_summary.json'), 'w'), indent=1)
+print(json.dumps({k: out[k] for k in out if k.startswith('solve_')}, indent=1))
