@@ -12,7 +12,7 @@
 #include "sdsm_common.h"
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
-                                        hipStream_t side1, hipStream_t side2, hipEvent_t *ev);
+                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev);
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
@@ -119,9 +119,9 @@ struct sdsm_plan {
     std::vector<float> psf;
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
-    int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hsave = 0;
+    int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hsave = 0, n_hglob = 0;
     size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0,
-           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_ell_nnz = 0, off_ell_hnz = 0, off_psf = 0, off_hsave = 0, total = 0;
+           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_ell_nnz = 0, off_ell_hnz = 0, off_psf = 0, off_hsave = 0, off_hglob = 0, total = 0;
 };
 
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -189,6 +189,8 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
         c.xi_off = p->total_xi; p->total_xi += c.Mcap;
         c.mask_off = p->total_mask_words; p->total_mask_words += ((int64_t)c.h * c.w + 31) / 32;
         c.hsave_slot = (6 + c.Mcap > 84) ? (int32_t)p->n_hsave++ : -1;
+        c.hglob_slot = (6 + c.Mcap > SDSM_MAX_N_LDS) ? (int32_t)p->n_hglob++ : -1;
+        c.pad = 0;
         c.perm_inv = perm_inverse((uint32_t)std::max<long>(N, 1));
         p->mask_info[4 * i] = r0; p->mask_info[4 * i + 1] = c0; p->mask_info[4 * i + 2] = c.h; p->mask_info[4 * i + 3] = c.w;
         p->mask_off_bytes[i] = c.mask_off * 4; p->xi_off[i] = c.xi_off; p->n_pixels[i] = c.N;
@@ -214,7 +216,8 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
     p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
-    p->off_hsave = take(8 * (size_t)std::max<int64_t>(p->n_hsave, 1) * (SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2));
+    p->off_hsave = take(8 * (size_t)std::max<int64_t>(p->n_hsave, 1) * (SDSM_MAX_N_LDS * (SDSM_MAX_N_LDS + 1) / 2));
+    p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1) * 2 * (SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2));
     p->total = o;
     return p;
 }
@@ -272,7 +275,7 @@ extern "C" int sdsm_set_debug_buffer(void *d_buf) { g_prof = (long long *)d_buf;
 
 // side streams / fork-join events of the three solve classes: one set per caller stream (created on first use, per
 // host thread), so that batches queued on different streams overlap instead of serialising on shared side streams
-struct SideSet { hipStream_t side[2]; hipEvent_t fj[3]; };
+struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; };
 static thread_local std::vector<std::pair<hipStream_t, SideSet>> g_sides;
 
 static thread_local int g_timing = 0;
@@ -319,7 +322,8 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_nnz = (uint16_t *)(b + p->off_ell_nnz); P.ell_hnz = (uint16_t *)(b + p->off_ell_hnz);
     P.hess_thr = 0.05f;   // same constant as the oracle's ORC_HESS_THR
     P.psf = (const float *)(b + p->off_psf);
-    P.hsave = (double *)(b + p->off_hsave); P.hsave_stride = SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2;
+    P.hsave = (double *)(b + p->off_hsave); P.hsave_stride = SDSM_MAX_N_LDS * (SDSM_MAX_N_LDS + 1) / 2;
+    P.hglob = (double *)(b + p->off_hglob); P.hglob_stride = 2 * (SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2);
     P.prof = g_prof;
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
@@ -329,12 +333,12 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     for (auto &kv : g_sides) if (kv.first == s) ss = &kv.second;
     if (!ss) {
         SideSet n{};
-        for (int i = 0; i < 2; i++) if ((e = hipStreamCreateWithFlags(&n.side[i], hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
-        for (int i = 0; i < 3; i++) if ((e = hipEventCreateWithFlags(&n.fj[i], hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
+        for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithFlags(&n.side[i], hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
+        for (int i = 0; i < 4; i++) if ((e = hipEventCreateWithFlags(&n.fj[i], hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
         g_sides.emplace_back(s, n);
         ss = &g_sides.back().second;
     }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], ss->fj)) != hipSuccess) return hipfail(e, "launch solve");
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], p->n_hglob > 0 ? ss->side[2] : nullptr, ss->fj)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }

@@ -20,7 +20,8 @@ typedef const uint16_t SDSM_GLOBAL *g_cu16_p;
 #define SDSM_MAX_LABELS 65535      // footprint bitset in LDS
 #define SDSM_MAX_BBOX_DIM 4096     // row / column rank tables in LDS
 #define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
-#define SDSM_MAX_N_SOLVE 172       // 6 + M handled by the largest solve class
+#define SDSM_MAX_N_LDS 172         // 6 + M of the largest class that keeps the Hessian in LDS
+#define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the largest solve class (Hessian + factor in global memory)
 
 #ifdef SDSM_PROFILE
 #define PROF_NOW() ((long long)__builtin_readcyclecounter())
@@ -44,6 +45,8 @@ struct CandDesc {
     int32_t Mcap;       // upper bound of M
     int32_t hsave_slot; // slot in the global Hessian-copy pool (only candidates that may reach the in-place class), else -1
     uint32_t perm_inv;  // crop position of the pixel with raster rank i is (i * perm_inv) mod N (low-discrepancy scatter)
+    int32_t hglob_slot; // slot in the global Hessian + factor pool of the largest class (6 + Mcap > SDSM_MAX_N_LDS), else -1
+    int32_t pad;
 };
 
 // Written by the setup kernel.
@@ -58,7 +61,7 @@ struct CandState {
     int32_t reserved;
 };
 static_assert(sizeof(CandState) == 64, "CandState layout");
-static_assert(sizeof(CandDesc) == 72, "CandDesc layout");
+static_assert(sizeof(CandDesc) == 80, "CandDesc layout");
 
 struct BatchParams {
     int32_t n, H, W, n_atoms;
@@ -83,6 +86,8 @@ struct BatchParams {
     const float *psf;
     double *hsave;                     // per-candidate Hessian copy for the in-place class
     int64_t hsave_stride;
+    double *hglob;                     // per-candidate Hessian + factor of the global-memory class
+    int64_t hglob_stride;
     long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 8 cycle counters per candidate
 };
 

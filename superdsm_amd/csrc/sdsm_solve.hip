@@ -37,9 +37,11 @@ namespace {
 #define HZREG 12         // leading ('significant') slots unrolled for the approximate Hessian
 
 // Compile-time LDS layout (offsets in doubles from the start of dynamic LDS).
-template <int NMAX, bool INPLACE>
+template <int NMAX, bool INPLACE, bool GLOBALH = false>
 struct Lay {
-    static constexpr int NP = NMAX * (NMAX + 1) / 2;
+    static constexpr bool GLOBAL_H = GLOBALH;      // Hessian and factor in global memory (largest class)
+    static constexpr int NP = GLOBALH ? 0 : NMAX * (NMAX + 1) / 2;
+    static constexpr int NPG = NMAX * (NMAX + 1) / 2;
     static constexpr int W = NMAX + 2;    // vectors are indexed up to n (right-hand-side row) inclusive
     static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
     static constexpr int RED = 7 * W, FLAG = RED + SDSM_WAVES * 32, HP = FLAG + 2;
@@ -66,12 +68,16 @@ struct Cand {                       // per-candidate global pointers (already of
     g_cu16_p ell_nnz;
     g_cu16_p ell_hnz;
     g_double_p hsave;
+    double *hglob;                      // flat pointer: Hessian (NPG doubles) followed by the factor (NPG doubles)
     int N, zmax, hzmax;
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
 };
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
+
+template <class L> __device__ __forceinline__ double *hess_ptr(const Cand &c) { if constexpr (L::GLOBAL_H) return c.hglob; else return SD + L::HP; }
+template <class L> __device__ __forceinline__ double *fact_ptr(const Cand &c) { if constexpr (L::GLOBAL_H) return c.hglob + L::NPG; else return SD + L::LP; }
 
 // loss terms of one pixel given t = y * S     (dsm.py:298-300, 306-310, 319-322, 344, 361-366)
 __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, double *r, double *dcurv)
@@ -153,7 +159,7 @@ template <class L>
 __device__ __forceinline__ double add_regulariser(const Cand &c, int M)
 {
     const double *xv = SD + L::X;
-    double *g = SD + L::G, *Hp = SD + L::HP;
+    double *g = SD + L::G, *Hp = hess_ptr<L>(c);
     double s2 = 0;
     for (int j = threadIdx.x; j < M; j += SDSM_WG) {
         double xi = xv[6 + j], t3 = xi * xi, t2 = sqrt(t3 + c.epsilon);
@@ -176,7 +182,7 @@ __device__ __noinline__ double eval_full_ell(const Cand &c PROF_PARAM)
 {
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
-    double *Hp = SD + L::HP, *g = SD + L::G;
+    double *Hp = hess_ptr<L>(c), *g = SD + L::G;
     const double *xv = SD + L::X;
     double red[28];
 #pragma unroll
@@ -225,7 +231,7 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M, np = n * (n + 1) / 2;
-    double *Hp = SD + L::HP, *g = SD + L::G;
+    double *Hp = hess_ptr<L>(c), *g = SD + L::G;
     const double *xv = SD + L::X;
     for (int e = tid; e < np; e += SDSM_WG) Hp[e] = 0;
     for (int i = tid; i < n; i += SDSM_WG) g[i] = 0;
@@ -351,7 +357,7 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
 {
     const int tid = threadIdx.x;
     const int np = n * (n + 1) / 2;
-    double *Hp = SD + L::HP, *Lp = SD + L::LP, *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *colj = SD + L::XT;   // XT is free between line searches
+    double *Hp = hess_ptr<L>(c), *Lp = fact_ptr<L>(c), *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *colj = SD + L::XT;   // XT is free between line searches
     int *flag = (int *)(SD + L::FLAG);
     bool finite = true;
     for (int i = tid; i < n; i += SDSM_WG) {
@@ -643,11 +649,11 @@ __device__ __forceinline__ void reparam(const double *th, double p0, double p1, 
 // NMAX: largest 6 + M this instantiation handles; candidates with 6 + M in (nmin_excl, NMAX] are processed,
 // the others are left to the other classes.  The smallest class also writes the records of trivial /
 // failed-setup candidates.
-template <int NMAX, bool INPLACE, int WPE>
+template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false>
 __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int nmin_excl, int handles_rest, sdsm_record *records,
                                                               uint32_t *masks, double *xi_out)
 {
-    using L = Lay<NMAX, INPLACE>;
+    using L = Lay<NMAX, INPLACE, GLOBALH>;
     const int tid = threadIdx.x;
     const int ci = P.order[blockIdx.x];
     const CandDesc cd = P.cand[ci];
@@ -668,12 +674,17 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
     if (6 + Mfull > SDSM_MAX_N_SOLVE) { unsupported = true; Mfull = 0; }     // elliptical result only (flagged)
     const int nfull = 6 + Mfull;
     if (!(nfull > nmin_excl && nfull <= NMAX)) return;
+    if (GLOBALH && cd.hglob_slot < 0) {                          // cannot happen (M <= Mcap); never touch a missing slot
+        if (tid == 0) { sdsm_record r0 = {}; r0.status = SDSM_CAND_UNSUPPORTED; r0.n_pixels = cd.N; r0.n_deform = st.M; *rec = r0; }
+        return;
+    }
 
     Cand c;
     c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0; c.hzmax = Mfull > 0 ? st.hzmax : 0;
     c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_nnz = (g_cu16_p)(P.ell_nnz + cd.crop_off); c.ell_hnz = (g_cu16_p)(P.ell_hnz + cd.crop_off);
     c.ell_idx = (g_cu16_p)(P.ell_idx + cd.ell_off); c.ell_w = (g_cfloat_p)(P.ell_w + cd.ell_off);
     c.hsave = (g_double_p)((INPLACE && cd.hsave_slot >= 0) ? P.hsave + (int64_t)cd.hsave_slot * P.hsave_stride : nullptr);
+    c.hglob = (GLOBALH && cd.hglob_slot >= 0) ? P.hglob + (int64_t)cd.hglob_slot * P.hglob_stride : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
     c.epsilon = P.epsilon; c.alpha = P.alpha;
     // local frame: centre of the bounding box, half extents
@@ -833,11 +844,11 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
 // class B: n <= 84   separate factor      LDS ~ 63 KB   (2 workgroups / CU)
 // class C: n <= 172  in-place factor      LDS ~ 130 KB  (1 workgroup / CU)
 // The three classes are independent: they run concurrently on three streams forked from the caller's stream.
-template <int NMAX, bool INPLACE, int WPE>
+template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false>
 static hipError_t launch_class(const BatchParams &P, int nmin_excl, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
-    auto kern = sdsm_k_solve<NMAX, INPLACE, WPE>;
-    constexpr int lds = Lay<NMAX, INPLACE>::TOTAL_BYTES;
+    auto kern = sdsm_k_solve<NMAX, INPLACE, WPE, GLOBALH>;
+    constexpr int lds = Lay<NMAX, INPLACE, GLOBALH>::TOTAL_BYTES;
     static_assert(lds <= 160 * 1024 - 512, "LDS budget");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
@@ -846,13 +857,19 @@ static hipError_t launch_class(const BatchParams &P, int nmin_excl, int handles_
 }
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
-                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipEvent_t *ev /* 3 */)
+                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */)
 {
     hipError_t e;
     // fork: the side streams wait for everything queued on the caller's stream so far (setup kernel)
     if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
+    if (side3) {   // candidates with 6 + M > 172: Hessian and factor in global memory (slow path, rare)
+        if ((e = hipStreamWaitEvent(side3, ev[0], 0)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, false, 1, true>(P, SDSM_MAX_N_LDS, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[3], side3)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
+    }
     if ((e = launch_class<172, true, 1>(P, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
     if ((e = launch_class<84, false, 2>(P, 40, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
     if ((e = launch_class<40, false, 2>(P, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;

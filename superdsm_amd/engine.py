@@ -131,7 +131,7 @@ class Batch:
         _capi.check(_capi.lib().sdsm_plan_layout(self.plan, lay.ctypes.data_as(C.c_void_p)), 'sdsm_plan_layout')
         ws = self.ws.cpu().numpy()
         zcap, npix, nell = int(lay[9]), int(lay[12]), int(lay[13])
-        state = ws[lay[1]:lay[1] + 64 * self.n].view(np.int32).reshape(self.n, 16)
+        state = ws[lay[1]:lay[1] + 64 * self.n].view(np.int32).reshape(self.n, 16)          # CandState, 64 B each
         crop_y = ws[lay[2]:lay[2] + 8 * npix].view(np.float64)
         crop_rc = ws[lay[3]:lay[3] + 4 * npix].view(np.uint32)
         crop_cc = ws[lay[4]:lay[4] + 4 * npix].view(np.uint32)

@@ -310,3 +310,29 @@ def test_preprocess_stage_in_pipeline(gpu):
     pl = pipeline.create_pipeline([Preprocessing()])
     data, _, _ = pl.process_image(d['g_raw'], config.Config({'preprocess': json.loads(str(d['cfg']))}), out='muted')
     np.testing.assert_allclose(data['y'], d['y'], rtol=0, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] / configs[3] stand-ins: large sigma_G (65x65 PSF), large regions, M up to ~300
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('workload', ['gowt1_like', 'nih3t3_like'])
+def test_large_scale_workloads_match_oracle(gpu, workload):
+    from oracle import oracle
+    from superdsm_amd import _capi, testing
+    scene = testing.make_scene(workload, max_size=3)
+    fps = scene['footprints']
+    res = testing.solve_scene_gpu(scene)
+    recs = res['records']
+    assert (recs['status'] == _capi.CAND_OPTIMAL).all(), np.unique(recs['status'], return_counts=True)
+    # every size class incl. the global-memory one (6 + M > 172) must be exercised by these scenes
+    n = recs['n_deform'] + 6
+    assert (n > 172).any() and ((n > 84) & (n <= 172)).any() and (n <= 40).any()
+    order = np.argsort(recs['n_pixels'])
+    sample = sorted(set([int(order[-1]), int(order[-2]), int(order[len(order) // 2]), int(order[0]), 0, len(fps) // 3]))
+    orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], [fps[i] for i in sample], scene['dsm_cfg'], nthreads=0)
+    for j, k in enumerate(sample):
+        assert (recs['n_pixels'][k], recs['n_deform'][k]) == (orecs['N'][j], orecs['M'][j])
+        tol = 1e-6 * orecs['N'][j] / 1000 + 1e-5 * abs(orecs['energy'][j])
+        assert abs(recs['energy'][k] - orecs['energy'][j]) <= tol, (k, recs['energy'][k], orecs['energy'][j])
+        assert testing.dice(res['fragments'][k][0], res['fragments'][k][1], orecs['fg_offset'][j], ofrags[j], scene['y'].shape) >= 0.999
+        assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][j])
