@@ -64,10 +64,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the DSM solve path has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a box with fewer GPUs than ranks: SDSM_BENCH_BACKEND=gloo shares the visible devices round-robin
+    backend = os.environ.get('SDSM_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from superdsm_amd import _capi, engine, testing
     from superdsm_amd import dist as sdist
@@ -87,10 +89,12 @@ def main():
 
     def step(i):
         k = i % nfl
+        if gathers[k] is not None:            # slot k's previous gather (default stream) must have read its buffers
+            streams[k].wait_stream(torch.cuda.default_stream())
         with torch.cuda.stream(streams[k]):
             batches[k].launch()
-        if gathers[k] is not None:
-            streams[k].synchronize()          # the collective runs on the process group's stream
+        if gathers[k] is not None:            # the gather is queued behind this step's kernels; the host does not block
+            torch.cuda.default_stream().wait_stream(streams[k])
             gathers[k].run()
 
     for i in range(args.warmup):

@@ -33,7 +33,13 @@ class RecordGather:
         dev = self.records.device
         sizes = torch.tensor([self.records.numel(), self.masks.numel()], dtype=torch.int64, device=dev)
         all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes, group=group)
+        if dist.get_backend(group) == 'gloo' and sizes.is_cuda:
+            cs = sizes.cpu()
+            all_cpu = [torch.zeros_like(cs) for _ in range(world)]
+            dist.all_gather(all_cpu, cs, group=group)
+            all_sizes = all_cpu
+        else:
+            dist.all_gather(all_sizes, sizes, group=group)
         self.sizes = torch.stack(all_sizes).cpu().numpy()
         self.pad = int(self.sizes.sum(axis=1).max())
         self.send = torch.zeros(self.pad, dtype=torch.uint8, device=dev)
@@ -43,6 +49,15 @@ class RecordGather:
         nr, nm = self.records.numel(), self.masks.numel()
         self.send[:nr].copy_(self.records.view(torch.uint8).reshape(-1))
         self.send[nr:nr + nm].copy_(self.masks.view(torch.uint8).reshape(-1))
+        if dist.get_backend(self.group) == 'gloo' and self.send.is_cuda:
+            # rehearsal path only (gloo has no CUDA gather): stage through the host
+            send = self.send.cpu()
+            recv = [torch.zeros_like(send) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(send, recv, dst=0, group=self.group)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.recv[r].copy_(recv[r])
+            return
         dist.gather(self.send, self.recv, dst=0, group=self.group)
 
     def unpack(self):

@@ -336,3 +336,68 @@ def test_large_scale_workloads_match_oracle(gpu, workload):
         assert abs(recs['energy'][k] - orecs['energy'][j]) <= tol, (k, recs['energy'][k], orecs['energy'][j])
         assert testing.dice(res['fragments'][k][0], res['fragments'][k][1], orecs['fg_offset'][j], ofrags[j], scene['y'].shape) >= 0.999
         assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][j])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# edge cases of the reference's per-candidate driver (objects.py:177-212) and of the operator's other callers
+# ---------------------------------------------------------------------------------------------------------
+def test_edge_cases_trivial_masked_border_and_elliptical_only(gpu):
+    from oracle import oracle
+    from superdsm_amd import _capi, engine, image, objects
+    rng = np.random.default_rng(5)
+    H, W = 96, 120
+    rr, cc = np.mgrid[:H, :W]
+    y = -0.2 + 0.02 * rng.standard_normal((H, W))
+    y = np.minimum(y, -0.01)
+    y[((rr - 30) / 11.0) ** 2 + ((cc - 40) / 15.0) ** 2 <= 1] = 0.35          # a nucleus
+    y[((rr - 70) / 9.0) ** 2 + ((cc - 4) / 12.0) ** 2 <= 1] = 0.3             # a nucleus cut by the image border
+    y[60, 90] = 0.4                                                           # a single positive pixel (noise)
+    atoms = np.ones((H, W), np.int32)
+    atoms[:, 70:] = 2
+    atoms[50:, :35] = 3
+    y_mask = np.ones((H, W), bool)
+    y_mask[25:35, 38:41] = False                                              # a hole in the mask inside the nucleus
+    cfg = dict(scale=1000, epsilon=1.0, alpha=0.033, smooth_amount=4, smooth_subsample=8, gaussian_shape_multiplier=2,
+               background_margin=8, init='elliptical')
+    fps = [[1], [2], [3], [1, 3]]
+    img = engine.DeviceImage(y, y_mask, atoms, cfg['background_margin'])
+    batch = engine.Batch(img, fps, cfg)
+    batch.launch()
+    gpu.cuda.synchronize()
+    recs = batch.records()
+    frags = batch.fragments(recs)
+    orecs, ofrags, _ = oracle.compute_objects(y, y_mask, atoms, fps, cfg, nthreads=0)
+    # [2]: exactly one positive pixel -> trivial (objects.py:184-191): energy 0, is_optimal False, fragment [[False]]
+    assert recs['status'][1] == _capi.CAND_TRIVIAL and orecs['status'][1] == 2 and recs['energy'][1] == 0
+    np.testing.assert_array_equal(frags[1][1], [[False]])
+    for k in (0, 2, 3):
+        assert recs['status'][k] == orecs['status'][k] == 0
+        assert (recs['n_pixels'][k], recs['n_deform'][k]) == (orecs['N'][k], orecs['M'][k])
+        tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
+        assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol
+        assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][k])
+        full = np.zeros((H, W), bool)
+        full[frags[k][0][0]:frags[k][0][0] + frags[k][1].shape[0], frags[k][0][1]:frags[k][0][1] + frags[k][1].shape[1]] = frags[k][1]
+        assert not (full & ~y_mask).any()                                    # masked-out pixels never enter a fragment
+    assert bool(recs['on_boundary'][2])                                       # the nucleus at the border reaches the pad ring
+    # the same through the reference-style API, incl. an empty batch and the in-place contract
+    yi = image.Image.create_from_array(y, normalize=False, mask=y_mask)
+    objs = []
+    for fp in fps:
+        o = objects.Object()
+        o.footprint = set(fp)
+        objs.append(o)
+    objects.compute_objects([], yi, atoms, cfg, None, out='muted')
+    objects.compute_objects(objs, yi, atoms, dict(cfg, cachesize=1, cp_timeout=300, smooth_mat_max_allocations=np.inf), None, out='muted')
+    assert objs[1].energy == 0 and objs[1].is_optimal is False and objs[0].is_optimal is True
+    assert abs(objs[0].energy - orecs['energy'][0]) <= 1e-5 * abs(orecs['energy'][0]) + 1e-6
+    # elliptical models only (smooth_amount = inf): what the reference's C2F stage asks of the operator (c2freganal.py:126)
+    cfg_inf = dict(cfg, smooth_amount=np.inf)
+    b2 = engine.Batch(img, [[1], [3]], cfg_inf)
+    b2.launch()
+    gpu.cuda.synchronize()
+    r2 = b2.records()
+    o2, _, _ = oracle.compute_objects(y, y_mask, atoms, [[1], [3]], cfg_inf, nthreads=0)
+    assert (r2['n_deform'] == 0).all() and (o2['M'] == 0).all()
+    np.testing.assert_allclose(r2['energy'], o2['energy'], rtol=1e-5, atol=1e-6)     # separable toy regions: psi ~ 1e-8
+    np.testing.assert_allclose(r2['energy'], r2['energy_ell'], rtol=1e-9, atol=1e-12)
