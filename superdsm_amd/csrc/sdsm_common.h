@@ -102,6 +102,7 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // Sum over the workgroup, result broadcast to every thread.  `scratch` holds >= SDSM_WAVES doubles.
+template <int WAVES = SDSM_WAVES>
 __device__ __forceinline__ double block_sum(double v, double *scratch)
 {
     v = wave_sum(v);
@@ -110,12 +111,12 @@ __device__ __forceinline__ double block_sum(double v, double *scratch)
     __syncthreads();
     double r = 0;
 #pragma unroll
-    for (int i = 0; i < SDSM_WAVES; i++) r += scratch[i];
+    for (int i = 0; i < WAVES; i++) r += scratch[i];
     return r;
 }
 
 // Sums K values over the workgroup with ONE barrier pair; results broadcast.  scratch: SDSM_WAVES * K doubles.
-template <int K>
+template <int K, int WAVES = SDSM_WAVES>
 __device__ __forceinline__ void block_sum_vec(double (&v)[K], double *scratch)
 {
 #pragma unroll
@@ -130,7 +131,7 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[K], double *scratch)
     for (int k = 0; k < K; k++) {
         double r = 0;
 #pragma unroll
-        for (int w = 0; w < SDSM_WAVES; w++) r += scratch[w * K + k];
+        for (int w = 0; w < WAVES; w++) r += scratch[w * K + k];
         v[k] = r;
     }
 }
@@ -151,6 +152,7 @@ __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v
     return r;
 }
 
+template <int WAVES = SDSM_WAVES>
 __device__ __forceinline__ int block_min_i32(int v, int *scratch)
 {
 #pragma unroll
@@ -160,7 +162,7 @@ __device__ __forceinline__ int block_min_i32(int v, int *scratch)
     __syncthreads();
     int r = scratch[0];
 #pragma unroll
-    for (int i = 1; i < SDSM_WAVES; i++) r = scratch[i] < r ? scratch[i] : r;
+    for (int i = 1; i < WAVES; i++) r = scratch[i] < r ? scratch[i] : r;
     return r;
 }
 

@@ -37,14 +37,15 @@ namespace {
 #define HZREG 12         // leading ('significant') slots unrolled for the approximate Hessian
 
 // Compile-time LDS layout (offsets in doubles from the start of dynamic LDS).
-template <int NMAX, bool INPLACE, bool GLOBALH = false>
+template <int NMAX, bool INPLACE, bool GLOBALH = false, int WGSIZE = 256>
 struct Lay {
+    static constexpr int WGS = WGSIZE, NWAVES = WGSIZE / 64;
     static constexpr bool GLOBAL_H = GLOBALH;      // Hessian and factor in global memory (largest class)
     static constexpr int NP = GLOBALH ? 0 : NMAX * (NMAX + 1) / 2;
     static constexpr int NPG = NMAX * (NMAX + 1) / 2;
     static constexpr int W = NMAX + 2;    // vectors are indexed up to n (right-hand-side row) inclusive
     static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
-    static constexpr int RED = 7 * W, FLAG = RED + SDSM_WAVES * 32, HP = FLAG + 2;
+    static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, HP = FLAG + 2;
     static constexpr int LP = INPLACE ? HP : HP + NP;
     static constexpr int END = LP + NP;
     static constexpr int TOTAL_BYTES = ((END * 8 + 15) / 16) * 16;
@@ -133,7 +134,7 @@ __device__ __noinline__ double eval_value(const Cand &c, int xo, int M)
 {
     const double *xv = SD + xo;
     double psi = 0;
-    for (int p = threadIdx.x; p < c.N; p += SDSM_WG) {
+    for (int p = threadIdx.x; p < c.N; p += L::WGS) {
         double yv = c.crop_y[p];
         uint32_t rc = c.crop_rc[p];
         double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
@@ -143,11 +144,11 @@ __device__ __noinline__ double eval_value(const Cand &c, int xo, int M)
         loss_terms(yv, S, &phi, &r, &dc);
         psi += phi;
     }
-    psi = block_sum(psi, SD + L::RED);
+    psi = block_sum<L::NWAVES>(psi, SD + L::RED);
     if (M > 0) {                                         // dsm.py:323-331
         double s2 = 0;
-        for (int j = threadIdx.x; j < M; j += SDSM_WG) s2 += sqrt(xv[6 + j] * xv[6 + j] + c.epsilon);
-        s2 = block_sum(s2, SD + L::RED);
+        for (int j = threadIdx.x; j < M; j += L::WGS) s2 += sqrt(xv[6 + j] * xv[6 + j] + c.epsilon);
+        s2 = block_sum<L::NWAVES>(s2, SD + L::RED);
         double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
         psi += o2 < 0 ? 0 : o2;
     }
@@ -161,14 +162,14 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M)
     const double *xv = SD + L::X;
     double *g = SD + L::G, *Hp = hess_ptr<L>(c);
     double s2 = 0;
-    for (int j = threadIdx.x; j < M; j += SDSM_WG) {
+    for (int j = threadIdx.x; j < M; j += L::WGS) {
         double xi = xv[6 + j], t3 = xi * xi, t2 = sqrt(t3 + c.epsilon);
         s2 += t2;
         g[6 + j] += c.alpha * (xi / t2);
         double gd = c.alpha * (1 / t2 - t3 / (t2 * t2 * t2));
         Hp[tri(6 + j, 6 + j)] += gd < 0 ? 0 : gd;
     }
-    s2 = block_sum(s2, SD + L::RED);
+    s2 = block_sum<L::NWAVES>(s2, SD + L::RED);
     double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
     return o2 < 0 ? 0 : o2;
 }
@@ -187,7 +188,7 @@ __device__ __noinline__ double eval_full_ell(const Cand &c PROF_PARAM)
     double red[28];
 #pragma unroll
     for (int k = 0; k < 28; k++) red[k] = 0;
-    for (int p = tid; p < c.N; p += SDSM_WG) {
+    for (int p = tid; p < c.N; p += L::WGS) {
         const double yv = c.crop_y[p];
         const uint32_t rc = c.crop_rc[p];
         const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
@@ -204,7 +205,7 @@ __device__ __noinline__ double eval_full_ell(const Cand &c PROF_PARAM)
             for (int b = 0; b <= a; b++) red[7 + a * (a + 1) / 2 + b] += dc * q[a] * q[b];   // static index: stays in registers
     }
     PROF_ADD(0, pt);
-    block_sum_vec<28>(red, SD + L::RED);
+    block_sum_vec<28, L::NWAVES>(red, SD + L::RED);
     if (tid < 6) {
         double gv = 0;
 #pragma unroll
@@ -233,15 +234,15 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
     const int n = 6 + M, np = n * (n + 1) / 2;
     double *Hp = hess_ptr<L>(c), *g = SD + L::G;
     const double *xv = SD + L::X;
-    for (int e = tid; e < np; e += SDSM_WG) Hp[e] = 0;
-    for (int i = tid; i < n; i += SDSM_WG) g[i] = 0;
+    for (int e = tid; e < np; e += L::WGS) Hp[e] = 0;
+    for (int i = tid; i < n; i += L::WGS) g[i] = 0;
     __syncthreads();
     double red[28];                                      // psi, g_theta[6], 6x6 lower triangle (21)
 #pragma unroll
     for (int k = 0; k < 28; k++) red[k] = 0;
     const int zm = M > 0 ? c.zmax : 0;
     const bool in_regs = zm <= ZREG;
-    for (int p = tid; p < c.N; p += SDSM_WG) {
+    for (int p = tid; p < c.N; p += L::WGS) {
         double yv = c.crop_y[p];
         uint32_t rc = c.crop_rc[p];
         double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
@@ -325,7 +326,7 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
         }
     }
     PROF_ADD(0, pt);
-    block_sum_vec<28>(red, SD + L::RED);
+    block_sum_vec<28, L::NWAVES>(red, SD + L::RED);
     if (tid < 6) {
         double gv = 0;
 #pragma unroll
@@ -360,13 +361,13 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
     double *Hp = hess_ptr<L>(c), *Lp = fact_ptr<L>(c), *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *colj = SD + L::XT;   // XT is free between line searches
     int *flag = (int *)(SD + L::FLAG);
     bool finite = true;
-    for (int i = tid; i < n; i += SDSM_WG) {
+    for (int i = tid; i < n; i += L::WGS) {
         double hii = Hp[tri(i, i)];
         if (!(hii > 0) || !isfinite(hii)) hii = 1;
         sc[i] = 1 / sqrt(hii);
         if (!isfinite(g[i])) finite = false;
     }
-    for (int e = tid; e < np; e += SDSM_WG) {
+    for (int e = tid; e < np; e += L::WGS) {
         double v = Hp[e];
         if (!isfinite(v)) finite = false;
         if (INPLACE) c.hsave[e] = v;
@@ -440,11 +441,12 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
     //      4 panel entries against it; then all 256 threads (16 x 16 grid) apply the rank-4 update to the trailing
     //      sub-matrix.  The right-hand side rides along as row n.
     constexpr int NB = 4;
+    constexpr int GR = L::WGS / 16;                             // thread grid GR x 16 over the trailing sub-matrix
     const int ri = tid >> 4, ki = tid & 15;
     double tau = 0;
     bool ok = false;
     for (int attempt = 0; attempt < 12 && !ok; attempt++) {
-        for (int i = ri; i < n; i += 16) {                        // scaled copy
+        for (int i = ri; i < n; i += GR) {                        // scaled copy
             const double si = sc[i];
             for (int k = ki; k <= i; k += 16) {
                 double v = (INPLACE ? c.hsave[tri(i, k)] : Hp[tri(i, k)]) * si * sc[k];
@@ -452,7 +454,7 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
                 Lp[tri(i, k)] = v;
             }
         }
-        for (int k = tid; k < n; k += SDSM_WG) yrow[k] = -g[k] * sc[k];
+        for (int k = tid; k < n; k += L::WGS) yrow[k] = -g[k] * sc[k];
         __syncthreads();
         ok = true;
         for (int j0 = 0; j0 < n; j0 += NB) {
@@ -494,7 +496,7 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
                 }
             }
             // 2. panel rows below the block: one thread per row, triangular solve against the block
-            for (int i = j0 + nb + tid; i <= n; i += SDSM_WG) {
+            for (int i = j0 + nb + tid; i <= n; i += L::WGS) {
                 double *row = i < n ? Lp + tri(i, j0) : yrow + j0;
                 double v[NB];
 #pragma unroll
@@ -512,7 +514,7 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
             __syncthreads();
             // 3. rank-nb update of the trailing sub-matrix (rows / columns >= j0 + nb; row n = right-hand side)
             const int jn = j0 + nb;
-            for (int i = jn + ri; i <= n; i += 16) {
+            for (int i = jn + ri; i <= n; i += GR) {
                 const double *pi = i < n ? Lp + tri(i, j0) : yrow + j0;
                 double li[NB];
 #pragma unroll
@@ -534,8 +536,8 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
     }
     if (!ok) return false;
     double l2 = 0;
-    for (int i = tid; i < n; i += SDSM_WG) l2 += yrow[i] * yrow[i];
-    l2 = block_sum(l2, SD + L::RED);
+    for (int i = tid; i < n; i += L::WGS) l2 += yrow[i] * yrow[i];
+    l2 = block_sum<L::NWAVES>(l2, SD + L::RED);
     // back substitution L^T z = yrow, blocked the same way: every thread solves the NB x NB block redundantly
     for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
         const int nb = n - j0 < NB ? n - j0 : NB;
@@ -553,7 +555,7 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
             for (int x2 = 0; x2 < NB; x2++) v = x2 == tid ? z[x2] : v;
             d[j0 + tid] = v;
         }
-        for (int i = tid; i < j0; i += SDSM_WG) {
+        for (int i = tid; i < j0; i += L::WGS) {
             double acc = yrow[i];
 #pragma unroll
             for (int cc = 0; cc < NB; cc++) if (cc < nb) acc -= Lp[tri(j0 + cc, i)] * z[cc];
@@ -562,7 +564,7 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
         __syncthreads();
     }
     bool fin = isfinite(l2);
-    for (int i = tid; i < n; i += SDSM_WG) { d[i] *= sc[i]; if (!isfinite(d[i])) fin = false; }
+    for (int i = tid; i < n; i += L::WGS) { d[i] *= sc[i]; if (!isfinite(d[i])) fin = false; }
     if (!fin) *flag = 1;
     __syncthreads();
     if (*flag) return false;
@@ -596,12 +598,12 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         if (lam2 * 0.5 <= NEWTON_ABSTOL + NEWTON_RELTOL * fabs(f)) {
             // converged: final full step, kept only if it does not increase f (near-separable regions have a
             // vanishing Hessian and the unguarded step can be arbitrarily bad)
-            for (int i = tid; i < n; i += SDSM_WG) xt[i] = x[i] + d[i];
+            for (int i = tid; i < n; i += L::WGS) xt[i] = x[i] + d[i];
             __syncthreads();
             const double psit = eval_value<L>(c, L::XT, M);
             (*ev_value)++;
             if (isfinite(psit) && c.scale * psit <= f) {
-                for (int i = tid; i < n; i += SDSM_WG) x[i] = xt[i];
+                for (int i = tid; i < n; i += L::WGS) x[i] = xt[i];
                 __syncthreads();
                 *psi_out = psit;
                 *iters_out = iters;
@@ -613,7 +615,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         double t = tprev * 2 < 1 ? tprev * 2 : 1;
         bool accepted = false;
         for (int ls = 0; ls < LS_MAX; ls++) {
-            for (int i = tid; i < n; i += SDSM_WG) xt[i] = x[i] + t * d[i];
+            for (int i = tid; i < n; i += L::WGS) xt[i] = x[i] + t * d[i];
             __syncthreads();
             double ft = c.scale * eval_value<L>(c, L::XT, M);
             (*ev_value)++;
@@ -623,7 +625,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         PROF_ADD(4, pt);
         if (!accepted) { status = 1; break; }
         tprev = t;
-        for (int i = tid; i < n; i += SDSM_WG) x[i] = xt[i];
+        for (int i = tid; i < n; i += L::WGS) x[i] = xt[i];
         __syncthreads();
     }
     *psi_out = eval_value<L>(c, L::X, M);
@@ -649,11 +651,11 @@ __device__ __forceinline__ void reparam(const double *th, double p0, double p1, 
 // NMAX: largest 6 + M this instantiation handles; candidates with 6 + M in (nmin_excl, NMAX] are processed,
 // the others are left to the other classes.  The smallest class also writes the records of trivial /
 // failed-setup candidates.
-template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false>
-__global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int nmin_excl, int handles_rest, sdsm_record *records,
+template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false, int WGSIZE = 256>
+__global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int nmin_excl, int handles_rest, sdsm_record *records,
                                                               uint32_t *masks, double *xi_out)
 {
-    using L = Lay<NMAX, INPLACE, GLOBALH>;
+    using L = Lay<NMAX, INPLACE, GLOBALH, WGSIZE>;
     const int tid = threadIdx.x;
     const int ci = P.order[blockIdx.x];
     const CandDesc cd = P.cand[ci];
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
 
     // ---- phases: 0 elliptical from zeros, 1 elliptical from the moment initialisation (only if phase 0 was
     //      not optimal, objects.py:337-355), 2 deformable shape model (objects.py:394-410) ---------------
-    for (int i = tid; i < NMAX; i += SDSM_WG) x[i] = 0;
+    for (int i = tid; i < NMAX; i += L::WGS) x[i] = 0;
     __syncthreads();
     double psi_ell = INFINITY, psi_final = NAN;
     bool have = false, fallback = false;
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
             if (P.init_elliptical && !have) { status_final = SDSM_CAND_ERROR; break; }   // CvxprogError (objects.py:351-353)
             M = Mfull;
             __syncthreads();
-            for (int i = tid; i < NMAX; i += SDSM_WG) x[i] = i < 6 ? keep[i] : 0;
+            for (int i = tid; i < NMAX; i += L::WGS) x[i] = i < 6 ? keep[i] : 0;
             __syncthreads();
         }
         double psi; int its;
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
             if (s == 2) fallback = true;                                        // exception -> fallback
             else if (s == 1) {                                                  // 'unknown' and worse than the start
                 __syncthreads();
-                for (int i = tid; i < NMAX; i += SDSM_WG) xt[i] = i < 6 ? keep[i] : 0;
+                for (int i = tid; i < NMAX; i += L::WGS) xt[i] = i < 6 ? keep[i] : 0;
                 __syncthreads();
                 double vi = eval_value<L>(c, L::XT, Mfull);
                 ev_value++;
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
             }
             if (fallback) {
                 __syncthreads();
-                for (int i = tid; i < NMAX; i += SDSM_WG) x[i] = i < 6 ? keep[i] : 0;
+                for (int i = tid; i < NMAX; i += L::WGS) x[i] = i < 6 ? keep[i] : 0;
                 __syncthreads();
                 psi_final = eval_value<L>(c, L::X, Mfull);
                 ev_value++;
@@ -784,12 +786,12 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
     // ---- mask tail (objects.py:198-209) ----------------------------------------------------------
     const int mwords = (cd.h * cd.w + 31) / 32;
     uint32_t *mk = masks + cd.mask_off;
-    for (int i = tid; i < mwords; i += SDSM_WG) mk[i] = 0;
+    for (int i = tid; i < mwords; i += L::WGS) mk[i] = 0;
     __syncthreads();
     int rmin = 1 << 30, rmax = -1, cmin = 1 << 30, cmax = -1;
     int onb = 0;
     if (status_final != SDSM_CAND_ERROR) {
-        for (int p = tid; p < c.N; p += SDSM_WG) {
+        for (int p = tid; p < c.N; p += L::WGS) {
             uint32_t rc = c.crop_rc[p];
             int pr = rc >> 16, pc = rc & 0xffffu;
             double u = ((double)pr - c.rmid) * c.inv_hr, v = ((double)pc - c.cmid) * c.inv_hc;
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
         }
         // 1-px pad ring of the image, polynomial part only (G~ has no rows there)
         const int ringw = P.W + 2, ringh = P.H + 2;
-        for (int i = tid; i < 2 * ringw + 2 * ringh; i += SDSM_WG) {
+        for (int i = tid; i < 2 * ringw + 2 * ringh; i += L::WGS) {
             int pr, pc;
             if (i < ringw) { pr = -1; pc = i - 1; }
             else if (i < 2 * ringw) { pr = P.H; pc = i - ringw - 1; }
@@ -816,11 +818,11 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
         }
     }
     int *ired = (int *)(SD + L::RED);
-    rmin = block_min_i32(rmin, ired); cmin = block_min_i32(cmin, ired);
-    rmax = -block_min_i32(-rmax, ired); cmax = -block_min_i32(-cmax, ired);
-    onb = -block_min_i32(-onb, ired);
+    rmin = block_min_i32<L::NWAVES>(rmin, ired); cmin = block_min_i32<L::NWAVES>(cmin, ired);
+    rmax = -block_min_i32<L::NWAVES>(-rmax, ired); cmax = -block_min_i32<L::NWAVES>(-cmax, ired);
+    onb = -block_min_i32<L::NWAVES>(-onb, ired);
 
-    if (xi_out) for (int j = tid; j < st.M; j += SDSM_WG) xi_out[cd.xi_off + j] = j < Mfull ? x[6 + j] : 0;
+    if (xi_out) for (int j = tid; j < st.M; j += L::WGS) xi_out[cd.xi_off + j] = j < Mfull ? x[6 + j] : 0;
     if (tid == 0) {
         // local basis -> full-image-normalised theta:  u = (x0 - O0) / P0
         double thl[6] = {x[0], x[1], x[2], x[3], x[4], x[5]}, thg[6];
@@ -844,15 +846,15 @@ __global__ __launch_bounds__(SDSM_WG, WPE) void sdsm_k_solve(BatchParams P, int 
 // class B: n <= 84   separate factor      LDS ~ 63 KB   (2 workgroups / CU)
 // class C: n <= 172  in-place factor      LDS ~ 130 KB  (1 workgroup / CU)
 // The three classes are independent: they run concurrently on three streams forked from the caller's stream.
-template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false>
+template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false, int WGSIZE = 256>
 static hipError_t launch_class(const BatchParams &P, int nmin_excl, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
-    auto kern = sdsm_k_solve<NMAX, INPLACE, WPE, GLOBALH>;
-    constexpr int lds = Lay<NMAX, INPLACE, GLOBALH>::TOTAL_BYTES;
+    auto kern = sdsm_k_solve<NMAX, INPLACE, WPE, GLOBALH, WGSIZE>;
+    constexpr int lds = Lay<NMAX, INPLACE, GLOBALH, WGSIZE>::TOTAL_BYTES;
     static_assert(lds <= 160 * 1024 - 512, "LDS budget");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(P.n), dim3(SDSM_WG), lds, stream, P, nmin_excl, handles_rest, records, masks, xi_out);
+    hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nmin_excl, handles_rest, records, masks, xi_out);
     return hipGetLastError();
 }
 
@@ -866,11 +868,11 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
     if (side3) {   // candidates with 6 + M > 172: Hessian and factor in global memory (slow path, rare)
         if ((e = hipStreamWaitEvent(side3, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_MAX_N_SOLVE, false, 1, true>(P, SDSM_MAX_N_LDS, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, false, 2, true, 512>(P, SDSM_MAX_N_LDS, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[3], side3)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
     }
-    if ((e = launch_class<172, true, 1>(P, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+    if ((e = launch_class<172, true, 2, false, 512>(P, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
     if ((e = launch_class<84, false, 2>(P, 40, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
     if ((e = launch_class<40, false, 2>(P, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join

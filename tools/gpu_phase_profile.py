@@ -25,9 +25,9 @@ recs = batch.records()
 p = prof.cpu().numpy().reshape(-1, 8).astype(np.float64)
 names = ['phaseA', 'phaseB', 'reduce', 'factor', 'linesrch', 'total', 'ell_tot']
 n = recs['n_deform'] + 6
-cls = np.where(n <= 40, 'A', np.where(n <= 84, 'B', 'C'))
+cls = np.where(n <= 40, 'A', np.where(n <= 84, 'B', np.where(n <= 172, 'C', 'D')))
 print('cycles are shader-clock ticks of thread 0; ms = ticks / 2.4e6 (approx)')
-for c in 'ABC':
+for c in 'ABCD':
     m = cls == c
     if not m.any():
         continue
