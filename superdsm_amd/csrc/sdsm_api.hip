@@ -12,7 +12,7 @@
 #include "sdsm_common.h"
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
-                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev);
+                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev, int n_c, int n_d);
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
@@ -115,7 +115,8 @@ struct sdsm_plan {
     sdsm_dsm_config cfg{};
     int k = 1, R = 0, zcap = 1, no_deform = 0;
     std::vector<CandDesc> cand;
-    std::vector<int32_t> fp_labels, order;
+    std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those that may reach class C, then class D
+    int n_order_c = 0, n_order_d = 0;
     std::vector<float> psf;
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
@@ -198,13 +199,17 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->order.resize(n);
     std::iota(p->order.begin(), p->order.end(), 0);
     std::stable_sort(p->order.begin(), p->order.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
+    // a candidate can only belong to a larger size class if its upper bound Mcap allows it: the larger classes get
+    // their own (shorter) launch lists instead of n workgroups that exit immediately
+    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > 84) { p->order.push_back(p->order[k]); p->n_order_c++; }
+    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_MAX_N_LDS) { p->order.push_back(p->order[k]); p->n_order_d++; }
     // workspace layout
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
     p->off_cand = take(sizeof(CandDesc) * std::max(n, 1));
     p->off_state = take(sizeof(CandState) * std::max(n, 1));
     p->off_fp = take(4 * std::max<size_t>(p->fp_labels.size(), 1));
-    p->off_order = take(4 * (size_t)std::max(n, 1));
+    p->off_order = take(4 * std::max<size_t>(p->order.size(), 1));
     p->off_psf = take(4 * p->psf.size());
     size_t np = (size_t)std::max<int64_t>(p->total_pixels, 1);
     p->off_crop_y = take(8 * np);
@@ -264,7 +269,7 @@ extern "C" int sdsm_batch_upload(const sdsm_plan *p, void *d_ws, size_t ws_bytes
     hipError_t e;
     if ((e = hipMemcpyAsync(b + p->off_cand, p->cand.data(), sizeof(CandDesc) * p->n, hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload cand");
     if (!p->fp_labels.empty() && (e = hipMemcpyAsync(b + p->off_fp, p->fp_labels.data(), 4 * p->fp_labels.size(), hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload footprints");
-    if ((e = hipMemcpyAsync(b + p->off_order, p->order.data(), 4 * (size_t)p->n, hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload order");
+    if ((e = hipMemcpyAsync(b + p->off_order, p->order.data(), 4 * p->order.size(), hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload order");
     if ((e = hipMemcpyAsync(b + p->off_psf, p->psf.data(), 4 * p->psf.size(), hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload psf");
     return SDSM_OK;
 }
@@ -338,7 +343,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
         g_sides.emplace_back(s, n);
         ss = &g_sides.back().second;
     }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], p->n_hglob > 0 ? ss->side[2] : nullptr, ss->fj)) != hipSuccess) return hipfail(e, "launch solve");
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], ss->side[2], ss->fj, p->n_order_c, p->n_order_d)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }

@@ -842,10 +842,10 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 }
 
 // ---- launch helper (called from sdsm_api.hip) ----------------------------------------------------
-// class A: n <= 40   separate factor      LDS ~ 17 KB   (2 workgroups / CU, register bound)
-// class B: n <= 84   separate factor      LDS ~ 63 KB   (2 workgroups / CU)
-// class C: n <= 172  in-place factor      LDS ~ 130 KB  (1 workgroup / CU)
-// The three classes are independent: they run concurrently on three streams forked from the caller's stream.
+// class AB: n <= 84   256 threads, separate factor     LDS ~ 63 KB   (2 workgroups / CU, register bound)
+// class C:  n <= 172  512 threads, in-place factor     LDS ~ 130 KB  (1 workgroup / CU)
+// class D:  n <= 1024 512 threads, Hessian + factor in global memory (slow path, only launched when needed)
+// The classes are independent: they run concurrently on streams forked from the caller's stream.
 template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false, int WGSIZE = 256>
 static hipError_t launch_class(const BatchParams &P, int nmin_excl, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
@@ -854,30 +854,39 @@ static hipError_t launch_class(const BatchParams &P, int nmin_excl, int handles_
     static_assert(lds <= 160 * 1024 - 512, "LDS budget");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
+    if (P.n <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nmin_excl, handles_rest, records, masks, xi_out);
     return hipGetLastError();
 }
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
-                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */)
+                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */,
+                                        int n_c, int n_d)
 {
+    (void)side2;
     hipError_t e;
+    // launch lists: P.order = [all n | the n_c candidates whose bound Mcap admits 6 + M > 84 | the n_d that admit > 172]
+    BatchParams Pc = P, Pd = P;
+    Pc.order = P.order + P.n; Pc.n = n_c;
+    Pd.order = P.order + P.n + n_c; Pd.n = n_d;
     // fork: the side streams wait for everything queued on the caller's stream so far (setup kernel)
-    if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
-    if (side3) {   // candidates with 6 + M > 172: Hessian and factor in global memory (slow path, rare)
+    if (n_c > 0 || n_d > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
+    if (n_d > 0) {   // 6 + M > 172: Hessian and factor in global memory (slow path)
         if ((e = hipStreamWaitEvent(side3, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_MAX_N_SOLVE, false, 2, true, 512>(P, SDSM_MAX_N_LDS, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, false, 2, true, 512>(Pd, SDSM_MAX_N_LDS, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[3], side3)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
     }
-    if ((e = launch_class<172, true, 2, false, 512>(P, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-    if ((e = launch_class<84, false, 2>(P, 40, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
-    if ((e = launch_class<40, false, 2>(P, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
+    if (n_c > 0) {
+        if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
+        if ((e = launch_class<172, true, 2, false, 512>(Pc, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
+    }
+    // 6 + M <= 84 in ONE launch on the caller's stream: the small sizes (<= 40) would not gain occupancy from a smaller LDS
+    // footprint (register bound at 2 workgroups / CU either way), and one stream less per batch means more batches fit
+    // the hardware queues
+    if ((e = launch_class<84, false, 2>(P, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
-    if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
-    if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
-    return hipStreamWaitEvent(stream, ev[2], 0);
+    if (n_d > 0 && (e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
+    if (n_c > 0 && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
+    return hipSuccess;
 }

@@ -401,3 +401,28 @@ def test_edge_cases_trivial_masked_border_and_elliptical_only(gpu):
     assert (r2['n_deform'] == 0).all() and (o2['M'] == 0).all()
     np.testing.assert_allclose(r2['energy'], o2['energy'], rtol=1e-5, atol=1e-6)     # separable toy regions: psi ~ 1e-8
     assert (r2['energy'] <= r2['energy_ell'] + 1e-9).all()
+
+
+def test_sharder_single_rank_equals_direct_batch(gpu):
+    """The multi-GPU code path (dist.Sharder: shard, solve on this rank's GPU, all-gather, unpack) with one rank."""
+    import torch.distributed as dist
+    from superdsm_amd import dist as sdist
+    from superdsm_amd import engine, testing
+    scene = testing.make_scene('synthetic256', max_size=2)
+    fps = scene['footprints']
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1)
+        created = True
+    try:
+        img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
+        cfg = {k: v for k, v in scene['dsm_cfg'].items() if k != 'background_margin'}
+        recs, frags = sdist.Sharder(device='cpu').solve(img, fps, cfg)
+        ref = testing.solve_scene_gpu(scene)
+        np.testing.assert_allclose(recs['energy'], ref['records']['energy'], rtol=1e-6, atol=1e-9)
+        for a, b in zip(frags, ref['fragments']):
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+    finally:
+        if created:
+            dist.destroy_process_group()
