@@ -274,27 +274,27 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             int64_t e = c.base + (int64_t)sl * cd.N;
             P.ell_idx[e] = 0; P.ell_w[e] = 0.f;
         }
-        // Order the row by descending weight (selection sort, ties keep the lower column index first): the solver's
-        // approximate Hessian uses only the leading entries >= hess_thr * row maximum; S and the gradient use all.
-        for (int a = 0; a < c.nnz; a++) {
-            int64_t ea = c.base + (int64_t)a * cd.N;
-            float wa = P.ell_w[ea]; uint16_t ia = P.ell_idx[ea];
-            int best = a; float wb = wa; uint16_t ib = ia;
-            for (int b = a + 1; b < c.nnz; b++) {
-                int64_t eb = c.base + (int64_t)b * cd.N;
-                float w2 = P.ell_w[eb]; uint16_t i2 = P.ell_idx[eb];
-                if (w2 > wb || (w2 == wb && i2 < ib)) { best = b; wb = w2; ib = i2; }
-            }
-            if (best != a) {
-                int64_t eb = c.base + (int64_t)best * cd.N;
-                P.ell_w[eb] = wa; P.ell_idx[eb] = ia;
-                P.ell_w[ea] = wb; P.ell_idx[ea] = ib;
-            }
-        }
+        // Partition the row: entries >= hess_thr * row maximum first (the solver's approximate Hessian uses only those;
+        // S and the gradient use all).  Two-pointer swap, O(nnz); the order inside the two parts is irrelevant.
         int hz = 0;
         if (c.nnz > 0) {
-            const float lim = P.hess_thr * P.ell_w[c.base];
-            while (hz < c.nnz && !(P.ell_w[c.base + (int64_t)hz * cd.N] < lim)) hz++;
+            float wmax = 0.f;
+            for (int a = 0; a < c.nnz; a++) { float w2 = P.ell_w[c.base + (int64_t)a * cd.N]; wmax = w2 > wmax ? w2 : wmax; }
+            const float lim = P.hess_thr * wmax;
+            int lo = 0, hi = c.nnz - 1;
+            while (lo <= hi) {
+                const int64_t el = c.base + (int64_t)lo * cd.N;
+                const float wl = P.ell_w[el];
+                if (!(wl < lim)) { lo++; continue; }
+                const int64_t eh = c.base + (int64_t)hi * cd.N;
+                const float wh = P.ell_w[eh];
+                if (wh < lim) { hi--; continue; }
+                const uint16_t il = P.ell_idx[el], ih = P.ell_idx[eh];
+                P.ell_w[el] = wh; P.ell_idx[el] = ih;
+                P.ell_w[eh] = wl; P.ell_idx[eh] = il;
+                lo++; hi--;
+            }
+            hz = lo;
         }
         P.ell_nnz[cd.crop_off + i] = (uint16_t)c.nnz;
         P.ell_hnz[cd.crop_off + i] = (uint16_t)hz;
