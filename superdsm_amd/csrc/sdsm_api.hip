@@ -121,8 +121,8 @@ struct sdsm_plan {
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
     int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hsave = 0, n_hglob = 0;
-    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0,
-           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_ell_nnz = 0, off_ell_hnz = 0, off_psf = 0, off_hsave = 0, off_hglob = 0, total = 0;
+    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_ell_meta = 0,
+           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_hsave = 0, off_hglob = 0, total = 0;
 };
 
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -164,8 +164,8 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
         p->R = p->k / 2;
         long per = (2 * p->R) / cfg->smooth_subsample + 1;
         long z = per * per;
-        p->zcap = (int)std::min<long>(z, 65535);
-    } else { p->psf.assign(1, 1.f); p->k = 1; p->R = 0; p->zcap = 1; }
+        p->zcap = (int)std::min<long>((z + 3) / 4 * 4, 4 * SDSM_MAX_ELL_GROUPS);   // groups of 4 entries; a solvable row has <= M <= 1018 entries
+    } else { p->psf.assign(1, 1.f); p->k = 1; p->R = 0; p->zcap = 4; }
     const int s = cfg->smooth_subsample;
     p->cand.resize(n); p->mask_info.resize((size_t)4 * n); p->mask_off_bytes.resize(n); p->xi_off.resize(n); p->n_pixels.resize(n);
     p->fp_labels.assign(labels, labels + (n > 0 ? offsets[n] : 0));
@@ -216,8 +216,9 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->off_crop_rc = take(4 * np);
     p->off_crop_cc = take(4 * np);
     p->off_dist = take(4 * np);
-    p->off_ell_nnz = take(2 * np);
-    p->off_ell_hnz = take(2 * np);
+    p->off_tmp_y = take(8 * np);
+    p->off_tmp_rc = take(4 * np);
+    p->off_ell_meta = take(4 * np);
     p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
     p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
@@ -253,8 +254,8 @@ extern "C" int sdsm_plan_layout(const sdsm_plan *p, int64_t *out)
 {
     if (!p || !out) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_layout: null argument");
     int64_t v[16] = {(int64_t)p->off_cand, (int64_t)p->off_state, (int64_t)p->off_crop_y, (int64_t)p->off_crop_rc, (int64_t)p->off_crop_cc,
-                     (int64_t)p->off_ell_nnz, (int64_t)p->off_grid, (int64_t)p->off_ell_idx, (int64_t)p->off_ell_w, p->zcap, p->k,
-                     (int64_t)sizeof(CandDesc), p->total_pixels, p->total_ell, 0, 0};
+                     (int64_t)p->off_ell_meta, (int64_t)p->off_grid, (int64_t)p->off_ell_idx, (int64_t)p->off_ell_w, p->zcap, p->k,
+                     (int64_t)sizeof(CandDesc), p->total_pixels, p->total_ell, (int64_t)sizeof(CandState), 0};
     memcpy(out, v, sizeof(v));
     return SDSM_OK;
 }
@@ -324,7 +325,8 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);
     P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);
     P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
-    P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_nnz = (uint16_t *)(b + p->off_ell_nnz); P.ell_hnz = (uint16_t *)(b + p->off_ell_hnz);
+    P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_meta = (uint32_t *)(b + p->off_ell_meta);
+    P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc);
     P.hess_thr = 0.05f;   // same constant as the oracle's ORC_HESS_THR
     P.psf = (const float *)(b + p->off_psf);
     P.hsave = (double *)(b + p->off_hsave); P.hsave_stride = SDSM_MAX_N_LDS * (SDSM_MAX_N_LDS + 1) / 2;

@@ -12,6 +12,10 @@ typedef double SDSM_GLOBAL *g_double_p;
 typedef const float SDSM_GLOBAL *g_cfloat_p;
 typedef const uint32_t SDSM_GLOBAL *g_cu32_p;
 typedef const uint16_t SDSM_GLOBAL *g_cu16_p;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 SDSM_GLOBAL *g_cf32x4_p;
+typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 
 #define SDSM_WG 256
 #define SDSM_WAVES (SDSM_WG / 64)
@@ -21,6 +25,8 @@ typedef const uint16_t SDSM_GLOBAL *g_cu16_p;
 #define SDSM_MAX_BBOX_DIM 4096     // row / column rank tables in LDS
 #define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
 #define SDSM_MAX_N_LDS 172         // 6 + M of the largest class that keeps the Hessian in LDS
+#define SDSM_ELL_GROUPS_REG 7       // groups of 4 G~ row entries the solve kernel keeps in registers (rows of <= 28 entries)
+#define SDSM_MAX_ELL_GROUPS 256    // zcap <= 1024 entries per row of G~ (a solvable candidate has M <= 1018 columns)
 #define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the largest solve class (Hessian + factor in global memory)
 
 #ifdef SDSM_PROFILE
@@ -35,8 +41,8 @@ enum { ST_OK = 0, ST_TRIVIAL = 2, ST_ERROR = 3, ST_UNSUPPORTED = 4 };
 
 // Host-planned description of one candidate (read-only on the device).
 struct CandDesc {
-    int64_t crop_off;   // first pixel of the candidate's packed crop (crop_y / crop_rc / crop_cc / ell_nnz)
-    int64_t ell_off;    // first entry of its ELL block (N * zcap entries, slot-major)
+    int64_t crop_off;   // first pixel of the candidate's packed crop (crop_y / crop_rc / crop_cc / ell_meta)
+    int64_t ell_off;    // first entry of its ELL block (N * zcap4 entries: groups of 4 slots, group-major)
     int64_t mask_off;   // first uint32 word of its bit-packed region-bbox mask
     int64_t xi_off;     // first entry of its grid / xi block (Mcap entries)
     int32_t N;          // region pixels (sum of the atoms' valid areas)
@@ -59,13 +65,14 @@ struct CandState {
     unsigned long long sum_r, sum_c, sum_rr, sum_cc;   // moments of the y > 0 pixels (image coordinates)
     int32_t hzmax;      // largest number of 'significant' entries (>= hess_thr * row maximum) in a row of G~
     int32_t reserved;
+    int32_t gcount[8];  // gcount[j] = crop positions whose row has more than 4 j entries (positions are sorted by that)
 };
-static_assert(sizeof(CandState) == 64, "CandState layout");
+static_assert(sizeof(CandState) == 96 && SDSM_ELL_GROUPS_REG <= 8, "CandState layout");
 static_assert(sizeof(CandDesc) == 80, "CandDesc layout");
 
 struct BatchParams {
     int32_t n, H, W, n_atoms;
-    int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, ELL slots per pixel
+    int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, ELL slots per pixel (a multiple of 4)
     int32_t no_deform;                 // smooth_amount == inf
     int32_t init_elliptical, max_iters, pad0;
     double scale, epsilon, alpha;
@@ -74,15 +81,19 @@ struct BatchParams {
     CandState *state;
     const int32_t *fp_labels;
     const int32_t *order;              // workgroup -> candidate (largest first)
-    double *crop_y;                    // 8 B / pixel
-    uint32_t *crop_rc;                 // (row << 16) | col, image coordinates: 4 B / pixel
-    uint32_t *crop_cc;                 // compressed coordinates (setup only)
-    uint32_t *dist;                    // chessboard distance to the nearest grid point (setup only)
+    double *crop_y;                    // 8 B / pixel, final crop order (rows with the most G~ entries first)
+    uint32_t *crop_rc;                 // (row << 16) | col, image coordinates: 4 B / pixel, final crop order
+    double *tmp_y;                     // setup only: the crop in scan order (low-discrepancy scatter of the raster rank)
+    uint32_t *tmp_rc;                  // setup only
+    uint32_t *crop_cc;                 // compressed coordinates (setup only, scan order)
+    uint32_t *dist;                    // setup only: chessboard distance to the nearest grid point, then the final crop position
     uint32_t *grid_rc;                 // sorted grid points, compressed coordinates
-    uint16_t *ell_idx;
+    // G~ rows: entry s of the row of crop position p is element ((s / 4) * N + p) * 4 + s % 4 of the candidate's block:
+    // one 16-byte (weights) + one 8-byte (column indices) load per lane fetches 4 entries, consecutive lanes read
+    // consecutive addresses
     float *ell_w;
-    uint16_t *ell_nnz;                 // number of non-zeros of the row
-    uint16_t *ell_hnz;                 // number of leading entries used by the solver's approximate Hessian
+    uint16_t *ell_idx;
+    uint32_t *ell_meta;                // entries of the row | entries used by the solver's approximate Hessian << 16
     const float *psf;
     double *hsave;                     // per-candidate Hessian copy for the in-place class
     int64_t hsave_stride;

@@ -1,4 +1,5 @@
-// Candidate setup: region crop, compressed coordinates, greedy sub-sample grid, G~ rows (ELL).
+// Candidate setup: region crop, compressed coordinates, greedy sub-sample grid, G~ rows (ELL, 4 entries per group,
+// crop positions sorted by the number of groups of their row).
 // One 256-thread workgroup per candidate.
 //
 // Reference behaviour restated here (never its code):
@@ -18,10 +19,13 @@ struct WeightCtx {
     const uint32_t *keys;   // sorted grid keys in LDS
     uint16_t *ell_idx;
     float *ell_w;
-    int64_t base;           // ell_off + pixel
+    int64_t base;           // ell_off + 4 * crop position
     int N, zcap, nnz;
     bool overflow;
 };
+
+// entry s of the row whose group-0 element starts at base (= ell_off + 4 * position)
+__device__ __forceinline__ int64_t ell_at(int64_t base, int N, int s) { return base + (int64_t)(s >> 2) * N * 4 + (s & 3); }
 
 __device__ __forceinline__ float wval(WeightCtx &c, int j)
 {
@@ -31,8 +35,9 @@ __device__ __forceinline__ float wval(WeightCtx &c, int j)
     if (adr <= c.R && adc <= c.R) {
         float v = c.psf[(c.R + dr) * c.k + (c.R + dc)];
         if (c.nnz < c.zcap) {
-            c.ell_idx[c.base + (int64_t)c.nnz * c.N] = (uint16_t)j;
-            c.ell_w[c.base + (int64_t)c.nnz * c.N] = v;
+            const int64_t e = ell_at(c.base, c.N, c.nnz);
+            c.ell_idx[e] = (uint16_t)j;
+            c.ell_w[e] = v;
         } else c.overflow = true;
         c.nnz++;
         return v;
@@ -104,6 +109,8 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     __shared__ unsigned long long scr64[SDSM_WAVES];
     __shared__ int scr32[SDSM_WAVES];
     __shared__ int sh_M, sh_npos, sh_err;
+    __shared__ int cls_cnt[SDSM_MAX_ELL_GROUPS + 1], cls_start[SDSM_MAX_ELL_GROUPS + 1], cls_run[SDSM_MAX_ELL_GROUPS + 1];
+    __shared__ int wave_cnt[SDSM_WAVES][SDSM_MAX_ELL_GROUPS + 1];
 
     const int tid = threadIdx.x;
     const int ci = P.order[blockIdx.x];
@@ -145,12 +152,13 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         int total;
         int pos = block_excl_count(flag, scr32, &total);
         if (flag) {
-            // crop position: low-discrepancy scatter of the raster rank (neighbouring positions are far apart in the
-            // image, which decorrelates the LDS atomics of the sparse Hessian accumulation in the solve kernel)
+            // scan order: low-discrepancy scatter of the raster rank (neighbouring positions are far apart in the image,
+            // which decorrelates the LDS atomics of the sparse Hessian accumulation in the solve kernel); the final
+            // crop order (step 4b) is this order, stably sorted by the size of the pixel's G~ row
             int64_t o = cd.crop_off + (int64_t)(((unsigned long long)(running + pos) * cd.perm_inv) % (unsigned long long)cd.N);
             if (running + pos < cd.N) {
-                P.crop_y[o] = yv;
-                P.crop_rc[o] = ((uint32_t)(cd.r0 + r) << 16) | (uint32_t)(cd.c0 + c);
+                P.tmp_y[o] = yv;
+                P.tmp_rc[o] = ((uint32_t)(cd.r0 + r) << 16) | (uint32_t)(cd.c0 + c);
             }
             atomicOr(&rowbits[r >> 5], 1u << (r & 31));
             atomicOr(&colbits[c >> 5], 1u << (c & 31));
@@ -186,17 +194,20 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     s.hc = hc; s.wc = wc; s.npos = sh_npos;
     s.sum_r = mom[0]; s.sum_c = mom[1]; s.sum_rr = mom[2]; s.sum_cc = mom[3];
     if (running != cd.N) { s.status = ST_ERROR; if (tid == 0) *st = s; return; }          // plan / image mismatch
-    if (s.npos == 1) { s.status = ST_TRIVIAL; if (tid == 0) *st = s; return; }            // objects.py:184-191
+    if (s.npos == 1) { s.status = ST_TRIVIAL; if (tid == 0) *st = s; return; }            // objects.py:184-191 (no solve)
 
     const int S = P.subsample, R = P.R;
     const bool null_matrix = P.no_deform || hc <= P.k / 2 || wc <= P.k / 2;               // dsm.py:187,225
     for (int i = tid; i < cd.N; i += SDSM_WG) {
-        uint32_t rc = P.crop_rc[cd.crop_off + i];
+        uint32_t rc = P.tmp_rc[cd.crop_off + i];
         int r = (int)(rc >> 16) - cd.r0, c = (int)(rc & 0xffffu) - cd.c0;
         uint32_t key = ((uint32_t)rowrank[r] << 16) | (uint32_t)colrank[c];
         P.crop_cc[cd.crop_off + i] = key;
-        if (null_matrix) { P.ell_nnz[cd.crop_off + i] = 0; P.ell_hnz[cd.crop_off + i] = 0; }
-        else if (rowrank[r] % S == 0 && colrank[c] % S == 0) {                             // dsm.py:165-168
+        if (null_matrix) {                              // no G~: the final crop order is the scan order
+            P.ell_meta[cd.crop_off + i] = 0;
+            P.crop_y[cd.crop_off + i] = P.tmp_y[cd.crop_off + i];
+            P.crop_rc[cd.crop_off + i] = rc;
+        } else if (rowrank[r] % S == 0 && colrank[c] % S == 0) {                             // dsm.py:165-168
             int j = atomicAdd(&sh_M, 1);
             if (j < SDSM_MAX_GRID) gridkeys[j] = key;
         }
@@ -244,6 +255,16 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     }
     if (unsupported) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
     __syncthreads();
+    if (6 + M > SDSM_MAX_N_SOLVE) {                      // the solve kernel only computes the elliptical model (flagged unsupported)
+        for (int i = tid; i < cd.N; i += SDSM_WG) {
+            P.ell_meta[cd.crop_off + i] = 0;
+            P.crop_y[cd.crop_off + i] = P.tmp_y[cd.crop_off + i];
+            P.crop_rc[cd.crop_off + i] = P.tmp_rc[cd.crop_off + i];
+        }
+        s.M = M; s.status = ST_OK;
+        if (tid == 0) *st = s;
+        return;
+    }
 
     // ---- 4. columns of G~ = grid points in raster order (np.nonzero(col_mask), dsm.py:159) ------
     for (int j = tid; j < M; j += SDSM_WG) {
@@ -256,22 +277,90 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     for (int j = tid; j < M; j += SDSM_WG) gridkeys[j] = P.grid_rc[cd.xi_off + j];
     __syncthreads();
 
+    // ---- 4b. final crop order: stable counting sort of the scan order by the number of 4-entry groups of the pixel's
+    //      G~ row, largest first.  A wavefront of the solve kernel then reads 64 rows of (nearly) the same length and
+    //      fetches only the groups that exist (CandState.gcount), instead of every row padded to the longest one. ------
+    const int ngmax = P.zcap / 4;                        // P.zcap is a multiple of 4, <= 4 * SDSM_MAX_ELL_GROUPS
+    for (int k = tid; k <= ngmax; k += SDSM_WG) { cls_cnt[k] = 0; cls_run[k] = 0; }
+    __syncthreads();
+    for (int i = tid; i < cd.N; i += SDSM_WG) {
+        uint32_t key = P.crop_cc[cd.crop_off + i];
+        const int cr = key >> 16, cc = key & 0xffffu;
+        int cnt = 0;
+        for (int j = 0; j < M; j++) {
+            int dr = (int)(gridkeys[j] >> 16) - cr, dc = (int)(gridkeys[j] & 0xffffu) - cc;
+            dr = dr < 0 ? -dr : dr; dc = dc < 0 ? -dc : dc;
+            cnt += (dr <= R && dc <= R) ? 1 : 0;
+        }
+        int k = (cnt + 3) >> 2;
+        k = k > ngmax ? ngmax : k;                       // rows longer than zcap are reported as errors in step 5
+        P.dist[cd.crop_off + i] = (uint32_t)k;
+        atomicAdd(&cls_cnt[k], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = ngmax; k >= 0; k--) { cls_start[k] = acc; acc += cls_cnt[k]; }
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int base = 0; base < cd.N; base += SDSM_WG) {
+            for (int e = tid; e < SDSM_WAVES * (ngmax + 1); e += SDSM_WG) wave_cnt[e / (ngmax + 1)][e % (ngmax + 1)] = 0;
+            __syncthreads();
+            const int i = base + tid;
+            const int k = i < cd.N ? (int)P.dist[cd.crop_off + i] : -1;
+            int within = 0;
+            unsigned long long todo = __ballot(k >= 0);
+            while (todo) {                               // one pass per distinct class present in the wavefront
+                const int src = __ffsll((long long)todo) - 1;
+                const int k0 = __shfl(k, src);
+                const unsigned long long same = __ballot(k == k0);
+                if (k == k0) {
+                    within = __popcll(same & ((1ull << lane) - 1ull));
+                    if (lane == src) wave_cnt[wave][k0] = __popcll(same);
+                }
+                todo &= ~same;
+            }
+            __syncthreads();
+            if (k >= 0) {
+                int before = 0;
+                for (int w2 = 0; w2 < wave; w2++) before += wave_cnt[w2][k];
+                P.dist[cd.crop_off + i] = (uint32_t)(cls_start[k] + cls_run[k] + before + within);
+            }
+            __syncthreads();
+            for (int k2 = tid; k2 <= ngmax; k2 += SDSM_WG) {
+                int add = 0;
+                for (int w2 = 0; w2 < SDSM_WAVES; w2++) add += wave_cnt[w2][k2];
+                cls_run[k2] += add;
+            }
+            __syncthreads();
+        }
+    }
+
     // ---- 5. rows of G~: PSF gather, float32 pairwise row sum, float32 division (dsm.py:192-193) --
     bool bad = false;
     int zmax = 0, hzmax = 0;
     for (int i = tid; i < cd.N; i += SDSM_WG) {
+        const int pos = (int)P.dist[cd.crop_off + i];
         uint32_t key = P.crop_cc[cd.crop_off + i];
         WeightCtx c;
         c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.keys = gridkeys;
-        c.ell_idx = P.ell_idx; c.ell_w = P.ell_w; c.base = cd.ell_off + i; c.N = cd.N; c.zcap = P.zcap; c.nnz = 0; c.overflow = false;
+        c.ell_idx = P.ell_idx; c.ell_w = P.ell_w; c.base = cd.ell_off + (int64_t)pos * 4; c.N = cd.N; c.zcap = P.zcap; c.nnz = 0; c.overflow = false;
+        P.crop_y[cd.crop_off + pos] = P.tmp_y[cd.crop_off + i];
+        P.crop_rc[cd.crop_off + pos] = P.tmp_rc[cd.crop_off + i];
         float sum = pw_sum(c, M);
-        if (c.overflow || !(sum > 0.f)) { bad = true; P.ell_nnz[cd.crop_off + i] = 0; P.ell_hnz[cd.crop_off + i] = 0; continue; }   // dsm.py:194
+        if (c.overflow || !(sum > 0.f)) { bad = true; P.ell_meta[cd.crop_off + pos] = 0; continue; }   // dsm.py:194
         for (int sl = 0; sl < c.nnz; sl++) {
-            int64_t e = c.base + (int64_t)sl * cd.N;
+            const int64_t e = ell_at(c.base, cd.N, sl);
             P.ell_w[e] = __fdiv_rn(P.ell_w[e], sum);
         }
-        for (int sl = c.nnz; sl < P.zcap; sl++) {           // padding: index 0, weight 0 (fixed-trip loops in the solve kernel)
-            int64_t e = c.base + (int64_t)sl * cd.N;
+        // padding (index 0, weight 0) up to the group count of the first position of this pixel's 64-position chunk: a
+        // wavefront of the solve kernel reads the groups its first lane needs for all of its lanes
+        int kh = 0;
+        { const int head = pos & ~63; for (int k2 = ngmax; k2 >= 0; k2--) if (cls_cnt[k2] > 0 && head >= cls_start[k2]) kh = k2; }
+        for (int sl = c.nnz; sl < 4 * kh; sl++) {
+            const int64_t e = ell_at(c.base, cd.N, sl);
             P.ell_idx[e] = 0; P.ell_w[e] = 0.f;
         }
         // Partition the row: entries >= hess_thr * row maximum first (the solver's approximate Hessian uses only those;
@@ -279,14 +368,14 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         int hz = 0;
         if (c.nnz > 0) {
             float wmax = 0.f;
-            for (int a = 0; a < c.nnz; a++) { float w2 = P.ell_w[c.base + (int64_t)a * cd.N]; wmax = w2 > wmax ? w2 : wmax; }
+            for (int a = 0; a < c.nnz; a++) { float w2 = P.ell_w[ell_at(c.base, cd.N, a)]; wmax = w2 > wmax ? w2 : wmax; }
             const float lim = P.hess_thr * wmax;
             int lo = 0, hi = c.nnz - 1;
             while (lo <= hi) {
-                const int64_t el = c.base + (int64_t)lo * cd.N;
+                const int64_t el = ell_at(c.base, cd.N, lo);
                 const float wl = P.ell_w[el];
                 if (!(wl < lim)) { lo++; continue; }
-                const int64_t eh = c.base + (int64_t)hi * cd.N;
+                const int64_t eh = ell_at(c.base, cd.N, hi);
                 const float wh = P.ell_w[eh];
                 if (wh < lim) { hi--; continue; }
                 const uint16_t il = P.ell_idx[el], ih = P.ell_idx[eh];
@@ -296,8 +385,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             }
             hz = lo;
         }
-        P.ell_nnz[cd.crop_off + i] = (uint16_t)c.nnz;
-        P.ell_hnz[cd.crop_off + i] = (uint16_t)hz;
+        P.ell_meta[cd.crop_off + pos] = (uint32_t)c.nnz | ((uint32_t)hz << 16);
         zmax = c.nnz > zmax ? c.nnz : zmax;
         hzmax = hz > hzmax ? hz : hzmax;
     }
@@ -306,6 +394,11 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     hzmax = -block_min_i32(-hzmax, scr32);
     __syncthreads();
     s.M = M; s.zmax = zmax; s.hzmax = hzmax;
+    for (int j = 0; j < 8; j++) {                        // positions [0, gcount[j]) have rows of more than 4 j entries
+        int acc = 0;
+        for (int k2 = j + 1; k2 <= ngmax; k2++) acc += cls_cnt[k2];
+        s.gcount[j] = acc;
+    }
     s.status = sh_err ? ST_ERROR : ST_OK;
     if (tid == 0) *st = s;
 }

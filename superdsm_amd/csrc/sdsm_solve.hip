@@ -33,7 +33,15 @@ namespace {
 #define LS_ALPHA 0.01
 #define LS_BETA 0.5
 #define LS_MAX 40
-#define ZREG 28          // ELL slots held in registers by the sparse path (covers zcap = 25 of the default ratios)
+#if defined(SDSM_PROFILE) && defined(SDSM_PROFILE_FINE)
+#define FINE_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define FINE_ADD(slot) do { FINE_FENCE(); long long _t = PROF_NOW(); prof_acc[slot] += _t - ft; ft = _t; } while (0)
+#define FINE_START() long long ft = PROF_NOW()
+#else
+#define FINE_ADD(slot) do { } while (0)
+#define FINE_START() do { } while (0)
+#endif
+#define ZREG (4 * SDSM_ELL_GROUPS_REG)   // ELL slots held in registers by the sparse path (covers zcap = 25 of the default ratios)
 #define HZREG 12         // leading ('significant') slots unrolled for the approximate Hessian
 
 // Compile-time LDS layout (offsets in doubles from the start of dynamic LDS).
@@ -64,10 +72,10 @@ struct Lay {
 struct Cand {                       // per-candidate global pointers (already offset) and scalars
     g_cdouble_p crop_y;
     g_cu32_p crop_rc;
-    g_cu16_p ell_idx;
-    g_cfloat_p ell_w;
-    g_cu16_p ell_nnz;
-    g_cu16_p ell_hnz;
+    g_cf32x4_p ell_w4;                  // group j of position p: element j * N + p (4 weights)
+    g_cu16x4_p ell_i4;                  // (4 column indices)
+    g_cu32_p ell_meta;                  // row entries | Hessian entries << 16
+    int gcount[SDSM_ELL_GROUPS_REG];    // positions [0, gcount[j]) have rows of more than 4 j entries
     g_double_p hsave;
     double *hglob;                      // flat pointer: Hessian (NPG doubles) followed by the factor (NPG doubles)
     int N, zmax, hzmax;
@@ -93,38 +101,56 @@ __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, dou
     *dcurv = yv * yv * (theta - theta * theta);
 }
 
-// G~ xi for pixel p.  Rows are padded with (index 0, weight 0) up to zmax, so the trip count is uniform; when the
-// row fits ZREG slots every load of the row is issued before the first use (memory-level parallelism: one wave
-// per SIMD has nothing else to hide the L2 latency behind).
+// Row of G~ for crop position p into registers.  Positions are sorted by row length (4-entry groups, longest first) and
+// rows are zero-padded to the group count of the first position of their 64-position chunk, so group j is fetched by a
+// wavefront iff its first position needs it: a uniform test against CandState.gcount, one 16-byte + one 8-byte load per
+// lane and group, all issued before the first use.
+__device__ __forceinline__ void load_row(const Cand &c, int p, float (&w)[ZREG], int (&id)[ZREG])
+{
+    const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
+#pragma unroll
+    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
+        if (q0 < c.gcount[j]) {
+            const f32x4 wv = c.ell_w4[(size_t)j * c.N + p];
+            const u16x4 iv = c.ell_i4[(size_t)j * c.N + p];
+            w[4 * j] = wv.x; w[4 * j + 1] = wv.y; w[4 * j + 2] = wv.z; w[4 * j + 3] = wv.w;
+            id[4 * j] = iv.x; id[4 * j + 1] = iv.y; id[4 * j + 2] = iv.z; id[4 * j + 3] = iv.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { w[4 * j + k] = 0.f; id[4 * j + k] = 0; }
+        }
+    }
+}
+
+__device__ __forceinline__ double gather_row(const Cand &c, const double *xv, int p, const float (&w)[ZREG], const int (&id)[ZREG])
+{
+    const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
+    double gx = 0;
+#pragma unroll
+    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
+        if (q0 < c.gcount[j]) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) gx += (double)w[4 * j + k] * xv[6 + id[4 * j + k]];
+        }
+    }
+    return gx;
+}
+
+// scalar accessors (rows longer than ZREG entries: generic slow path)
+__device__ __forceinline__ float ell_w_at(const Cand &c, int s, int p) { return ((g_cfloat_p)c.ell_w4)[((size_t)(s >> 2) * c.N + p) * 4 + (s & 3)]; }
+__device__ __forceinline__ int ell_i_at(const Cand &c, int s, int p) { return ((g_cu16_p)c.ell_i4)[((size_t)(s >> 2) * c.N + p) * 4 + (s & 3)]; }
+
+// G~ xi for crop position p
 __device__ __forceinline__ double smooth_term(const Cand &c, const double *xv, int p)
 {
-    double gx = 0;
     if (c.zmax <= ZREG) {
         float w[ZREG]; int id[ZREG];
-#pragma unroll
-        for (int s = 0; s < ZREG; s++) {            // branch free: clamp the slot (uniform), select the weight
-            const int se = s < c.zmax ? s : c.zmax - 1;
-            const size_t o = (size_t)se * c.N + p;
-            const float wv = c.ell_w[o];
-            id[s] = c.ell_idx[o];
-            w[s] = s < c.zmax ? wv : 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < ZREG; s++) gx += (double)w[s] * xv[6 + id[s]];
-        return gx;
+        load_row(c, p, w, id);
+        return gather_row(c, xv, p, w, id);
     }
-    for (int s0 = 0; s0 < c.zmax; s0 += 4) {
-        float w[4]; int id[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int s = s0 + k < c.zmax ? s0 + k : c.zmax - 1;
-            size_t o = (size_t)s * c.N + p;
-            w[k] = s0 + k < c.zmax ? c.ell_w[o] : 0.f;
-            id[k] = c.ell_idx[o];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) gx += (double)w[k] * xv[6 + id[k]];
-    }
+    const int nnz = (int)(c.ell_meta[p] & 0xffffu);
+    double gx = 0;
+    for (int s = 0; s < nnz; s++) gx += (double)ell_w_at(c, s, p) * xv[6 + ell_i_at(c, s, p)];
     return gx;
 }
 
@@ -243,27 +269,21 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
     const int zm = M > 0 ? c.zmax : 0;
     const bool in_regs = zm <= ZREG;
     for (int p = tid; p < c.N; p += L::WGS) {
+        FINE_START();
         double yv = c.crop_y[p];
         uint32_t rc = c.crop_rc[p];
         double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
         double q[6] = {u * u, v * v, 2 * (u * v), 2 * u, 2 * v, 1.0};
         double Sv = q[0] * xv[0] + q[1] * xv[1] + q[2] * xv[2] + q[3] * xv[3] + q[4] * xv[4] + xv[5];
-        const int nnz = M > 0 ? (int)c.ell_nnz[p] : 0;
+        const uint32_t meta = M > 0 ? c.ell_meta[p] : 0u;
+        const int nnz = (int)(meta & 0xffffu);
         float w[ZREG]; int id[ZREG];
         if (in_regs) {
-#pragma unroll
-            for (int s = 0; s < ZREG; s++) {
-                const int se = s < zm ? s : (zm > 0 ? zm - 1 : 0);
-                const size_t o = (size_t)se * c.N + p;
-                const float wv = zm > 0 ? c.ell_w[o] : 0.f;
-                id[s] = zm > 0 ? (int)c.ell_idx[o] : 0;
-                w[s] = s < zm ? wv : 0.f;
-            }
-            double gx = 0;
-#pragma unroll
-            for (int s = 0; s < ZREG; s++) gx += (double)w[s] * xv[6 + id[s]];
-            Sv += gx;
+            load_row(c, p, w, id);
+            FINE_ADD(8);
+            Sv += gather_row(c, xv, p, w, id);
         } else if (M > 0) Sv += smooth_term(c, xv, p);
+        FINE_ADD(9);
         double phi, r, dc;
         loss_terms(yv, Sv, &phi, &r, &dc);
         red[0] += phi;
@@ -273,12 +293,20 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
         for (int a = 0; a < 6; a++)
 #pragma unroll
             for (int b = 0; b <= a; b++) red[7 + a * (a + 1) / 2 + b] += dc * q[a] * q[b];
+        FINE_ADD(10);
         if (dc != 0 || r != 0) {
-            const int hnz = M > 0 ? (int)c.ell_hnz[p] : 0;
+            const int hnz = (int)(meta >> 16);
             if (in_regs) {
+                const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
 #pragma unroll
-                for (int a = 0; a < ZREG; a++)
-                    if (a < nnz) atomicAdd(&g[6 + id[a]], r * (double)w[a]);          // exact gradient: every entry
+                for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
+                    if (q0 < c.gcount[j]) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (4 * j + k < nnz) atomicAdd(&g[6 + id[4 * j + k]], r * (double)w[4 * j + k]);   // exact gradient: every entry
+                    }
+                }
+                FINE_ADD(11);
                 if (c.hzmax <= HZREG) {
 #pragma unroll
                     for (int a = 0; a < HZREG; a++) {                                    // approximate Hessian: leading entries
@@ -297,33 +325,32 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
                     }
                 } else {
                     for (int a = 0; a < hnz; a++) {
-                        const double dwa = dc * (double)c.ell_w[(size_t)a * c.N + p];
-                        const int ra = 6 + c.ell_idx[(size_t)a * c.N + p];
+                        const double dwa = dc * (double)ell_w_at(c, a, p);
+                        const int ra = 6 + ell_i_at(c, a, p);
                         double *Hrow = Hp + tri(ra, 0);
                         for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
                         for (int b = 0; b <= a; b++) {
-                            const int rb = 6 + c.ell_idx[(size_t)b * c.N + p];
-                            atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)c.ell_w[(size_t)b * c.N + p]);
+                            const int rb = 6 + ell_i_at(c, b, p);
+                            atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)ell_w_at(c, b, p));
                         }
                     }
                 }
             } else {
                 for (int a = 0; a < nnz; a++) {
-                    size_t oa = (size_t)a * c.N + p;
-                    const double wa = (double)c.ell_w[oa], dwa = dc * wa;
-                    const int ra = 6 + c.ell_idx[oa];
+                    const double wa = (double)ell_w_at(c, a, p), dwa = dc * wa;
+                    const int ra = 6 + ell_i_at(c, a, p);
                     atomicAdd(&g[ra], r * wa);
                     if (a >= hnz) continue;
                     double *Hrow = Hp + tri(ra, 0);
                     for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
                     for (int b = 0; b <= a; b++) {
-                        size_t ob = (size_t)b * c.N + p;
-                        const int rb = 6 + c.ell_idx[ob];
-                        atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)c.ell_w[ob]);
+                        const int rb = 6 + ell_i_at(c, b, p);
+                        atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)ell_w_at(c, b, p));
                     }
                 }
             }
         }
+        FINE_ADD(12);
     }
     PROF_ADD(0, pt);
     block_sum_vec<28, L::NWAVES>(red, SD + L::RED);
@@ -683,8 +710,10 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 
     Cand c;
     c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0; c.hzmax = Mfull > 0 ? st.hzmax : 0;
-    c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_nnz = (g_cu16_p)(P.ell_nnz + cd.crop_off); c.ell_hnz = (g_cu16_p)(P.ell_hnz + cd.crop_off);
-    c.ell_idx = (g_cu16_p)(P.ell_idx + cd.ell_off); c.ell_w = (g_cfloat_p)(P.ell_w + cd.ell_off);
+    c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
+    c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
+#pragma unroll
+    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = Mfull > 0 ? st.gcount[j] : 0;
     c.hsave = (g_double_p)((INPLACE && cd.hsave_slot >= 0) ? P.hsave + (int64_t)cd.hsave_slot * P.hsave_stride : nullptr);
     c.hglob = (GLOBALH && cd.hglob_slot >= 0) ? P.hglob + (int64_t)cd.hglob_slot * P.hglob_stride : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
@@ -699,7 +728,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     double *x = SD + L::X, *xt = SD + L::XT;
 
 #ifdef SDSM_PROFILE
-    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long prof_t_start = PROF_NOW();
 #endif
     sdsm_record r = {};
@@ -834,7 +863,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         r.on_boundary = onb;
 #ifdef SDSM_PROFILE
         prof_acc[5] = PROF_NOW() - prof_t_start;
-        if (P.prof) for (int i = 0; i < 8; i++) P.prof[(size_t)ci * 8 + i] = prof_acc[i];
+        if (P.prof) for (int i = 0; i < 16; i++) P.prof[(size_t)ci * 16 + i] = prof_acc[i];
 #endif
         if (rmax >= 0) { r.fg_r0 = rmin; r.fg_c0 = cmin; r.fg_h = rmax - rmin + 1; r.fg_w = cmax - cmin + 1; }
         *rec = r;

@@ -130,12 +130,11 @@ class Batch:
         lay = np.zeros(16, np.int64)
         _capi.check(_capi.lib().sdsm_plan_layout(self.plan, lay.ctypes.data_as(C.c_void_p)), 'sdsm_plan_layout')
         ws = self.ws.cpu().numpy()
-        zcap, npix, nell = int(lay[9]), int(lay[12]), int(lay[13])
-        state = ws[lay[1]:lay[1] + 64 * self.n].view(np.int32).reshape(self.n, 16)          # CandState, 64 B each
+        zcap, npix, nell, ssz = int(lay[9]), int(lay[12]), int(lay[13]), int(lay[14])
+        state = ws[lay[1]:lay[1] + ssz * self.n].view(np.int32).reshape(self.n, ssz // 4)   # CandState
         crop_y = ws[lay[2]:lay[2] + 8 * npix].view(np.float64)
         crop_rc = ws[lay[3]:lay[3] + 4 * npix].view(np.uint32)
-        crop_cc = ws[lay[4]:lay[4] + 4 * npix].view(np.uint32)
-        ell_nnz = ws[lay[5]:lay[5] + 2 * npix].view(np.uint16)
+        ell_meta = ws[lay[5]:lay[5] + 4 * npix].view(np.uint32)
         xi_off = self.xi_offsets()
         grid = ws[lay[6]:].view(np.uint32)
         ell_idx = ws[lay[7]:lay[7] + 2 * nell].view(np.uint16)
@@ -146,23 +145,27 @@ class Batch:
             N = int(self.n_pixels[i])
             M, status, hc, wc, npos = (int(v) for v in state[i, :5])
             rc = crop_rc[po:po + N]
-            cc = crop_cc[po:po + N]
             g = grid[xi_off[i]:xi_off[i] + M]
             eo = po * zcap
-            nnz = ell_nnz[po:po + N].astype(np.int64)
-            idx = ell_idx[eo:eo + N * zcap].reshape(zcap, N).astype(np.int64) if N else np.zeros((zcap, 0), np.int64)
-            w = ell_w[eo:eo + N * zcap].reshape(zcap, N) if N else np.zeros((zcap, 0), np.float32)
-            # rows are stored by descending weight (the solver's Hessian uses the leading entries); report them by column
+            nnz = (ell_meta[po:po + N] & 0xffff).astype(np.int64)
+            hnz = (ell_meta[po:po + N] >> 16).astype(np.int64)
+            # entry s of position p: element ((s // 4) * N + p) * 4 + s % 4  ->  [slot, position]
+            unpack = lambda a: a[eo:eo + N * zcap].reshape(zcap // 4, N, 4).transpose(0, 2, 1).reshape(zcap, N)
+            idx = unpack(ell_idx).astype(np.int64) if N else np.zeros((zcap, 0), np.int64)
+            w = unpack(ell_w) if N else np.zeros((zcap, 0), np.float32)
+            live = np.arange(zcap)[:, None] < nnz[None, :]       # slots past the row's end hold padding or nothing
+            idx, w = np.where(live, idx, 0), np.where(live, w, np.float32(0))
+            # the entries used by the solver's Hessian come first in a row; report rows by column index
             key = np.where(np.arange(zcap)[:, None] < nnz[None, :], idx, 1 << 30)
             srt = np.argsort(key, axis=0, kind='stable')
             idx = np.take_along_axis(idx, srt, axis=0)
             w = np.take_along_axis(w, srt, axis=0)
-            # the crop is stored in a scattered order (CandDesc.perm_inv); report it in raster order
+            # the crop is stored by descending row length (scan order = a scatter of the raster order); report it in raster order
             o = np.lexsort(((rc & 0xffff), (rc >> 16)))
             out.append(dict(N=N, M=M, status=status, hc=hc, wc=wc, npos=npos, zmax=int(state[i, 5]), y=crop_y[po:po + N][o].copy(),
                             r=(rc >> 16).astype(np.int64)[o], c=(rc & 0xffff).astype(np.int64)[o],
-                            cr=(cc >> 16).astype(np.int64)[o], cc=(cc & 0xffff).astype(np.int64)[o],
-                            grid_r=(g >> 16).astype(np.int64), grid_c=(g & 0xffff).astype(np.int64), nnz=nnz[o], idx=idx[:, o].copy(), w=w[:, o].copy()))
+                            grid_r=(g >> 16).astype(np.int64), grid_c=(g & 0xffff).astype(np.int64), nnz=nnz[o], hnz=hnz[o],
+                            nnz_stored_order=nnz.copy(), idx=idx[:, o].copy(), w=w[:, o].copy()))
             po += N
         return out
 

@@ -16,13 +16,13 @@ scene = testing.make_scene(wl, max_size=3)
 fps = scene['footprints']
 img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
 batch = engine.Batch(img, fps, scene['dsm_cfg'])
-prof = torch.zeros(len(fps) * 8, dtype=torch.int64, device='cuda')
+prof = torch.zeros(len(fps) * 16, dtype=torch.int64, device='cuda')
 _capi.lib().sdsm_set_debug_buffer(C.c_void_p(prof.data_ptr()))
 for _ in range(2):
     batch.launch()
 torch.cuda.synchronize()
 recs = batch.records()
-p = prof.cpu().numpy().reshape(-1, 8).astype(np.float64)
+p = prof.cpu().numpy().reshape(-1, 16).astype(np.float64)
 names = ['phaseA', 'phaseB', 'reduce', 'factor', 'linesrch', 'total', 'ell_tot']
 n = recs['n_deform'] + 6
 cls = np.where(n <= 40, 'A', np.where(n <= 84, 'B', np.where(n <= 172, 'C', 'D')))
@@ -39,6 +39,8 @@ for c in 'ABCD':
         print('   %-9s share of total: %.1f%%   per full eval (median): %.1f us' % (nm, 100 * p[m, i].sum() / tot.sum(), np.median(p[m, i] / np.maximum(recs['evals_full'][m], 1)) / 2400))
     print('   elliptical share: %.1f%%' % (100 * p[m, 6].sum() / tot.sum()))
 worst = np.argsort(-p[:, 5])[:8]
+if p[:, 8:13].sum() > 0:
+    print('fine sections of the sparse pixel pass (thread 0, fenced): loads %.1f%%  gather %.1f%%  loss+sums %.1f%%  grad atomics %.1f%%  hess atomics %.1f%%' % tuple(100 * p[:, 8:13].sum(0) / p[:, 8:13].sum()))
 print('slowest candidates:')
 for k in worst:
     print('  cand %d N=%d M=%d it_ell=%d it_dsm=%d evals=%d/%d total=%.2f ms  A=%.2f B=%.2f red=%.2f fac=%.2f ls=%.2f' % (
