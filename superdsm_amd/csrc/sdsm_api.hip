@@ -122,7 +122,7 @@ struct sdsm_plan {
     std::vector<int64_t> mask_off_bytes, xi_off;
     int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hsave = 0, n_hglob = 0;
     size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_ell_meta = 0,
-           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_hsave = 0, off_hglob = 0, total = 0;
+           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, total = 0;
 };
 
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -189,8 +189,8 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
         c.ell_off = p->total_ell; p->total_ell += (int64_t)N * p->zcap;
         c.xi_off = p->total_xi; p->total_xi += c.Mcap;
         c.mask_off = p->total_mask_words; p->total_mask_words += ((int64_t)c.h * c.w + 31) / 32;
-        c.hsave_slot = (6 + c.Mcap > 84) ? (int32_t)p->n_hsave++ : -1;
-        c.hglob_slot = (6 + c.Mcap > SDSM_MAX_N_LDS) ? (int32_t)p->n_hglob++ : -1;
+        c.hsave_slot = -1;
+        c.hglob_slot = (6 + c.Mcap > SDSM_ENV_DENSE_N) ? (int32_t)p->n_hglob++ : -1;
         c.pad = 0;
         c.perm_inv = perm_inverse((uint32_t)std::max<long>(N, 1));
         p->mask_info[4 * i] = r0; p->mask_info[4 * i + 1] = c0; p->mask_info[4 * i + 2] = c.h; p->mask_info[4 * i + 3] = c.w;
@@ -201,8 +201,8 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     std::stable_sort(p->order.begin(), p->order.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
     // a candidate can only belong to a larger size class if its upper bound Mcap allows it: the larger classes get
     // their own (shorter) launch lists instead of n workgroups that exit immediately
-    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > 84) { p->order.push_back(p->order[k]); p->n_order_c++; }
-    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_MAX_N_LDS) { p->order.push_back(p->order[k]); p->n_order_d++; }
+    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_K1_DENSE_N) { p->order.push_back(p->order[k]); p->n_order_c++; }
+    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_ENV_DENSE_N) { p->order.push_back(p->order[k]); p->n_order_d++; }
     // workspace layout
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
@@ -222,8 +222,9 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
     p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
-    p->off_hsave = take(8 * (size_t)std::max<int64_t>(p->n_hsave, 1) * (SDSM_MAX_N_LDS * (SDSM_MAX_N_LDS + 1) / 2));
-    p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1) * 2 * (SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2));
+    p->off_env_fst = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
+    p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
+    p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1) * (SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2));
     p->total = o;
     return p;
 }
@@ -329,8 +330,8 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc);
     P.hess_thr = 0.05f;   // same constant as the oracle's ORC_HESS_THR
     P.psf = (const float *)(b + p->off_psf);
-    P.hsave = (double *)(b + p->off_hsave); P.hsave_stride = SDSM_MAX_N_LDS * (SDSM_MAX_N_LDS + 1) / 2;
-    P.hglob = (double *)(b + p->off_hglob); P.hglob_stride = 2 * (SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2);
+    P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
+    P.hglob = (double *)(b + p->off_hglob); P.hglob_stride = SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2;
     P.prof = g_prof;
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");

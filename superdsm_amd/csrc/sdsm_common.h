@@ -24,7 +24,11 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_MAX_LABELS 65535      // footprint bitset in LDS
 #define SDSM_MAX_BBOX_DIM 4096     // row / column rank tables in LDS
 #define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
-#define SDSM_MAX_N_LDS 172         // 6 + M of the largest class that keeps the Hessian in LDS
+#define SDSM_K1_NMAX 128           // solve class 1: 6 + M <= 128 and envelope <= SDSM_K1_EMAX doubles (LDS ~ 30 KB)
+#define SDSM_K1_EMAX 2560
+#define SDSM_K2_EMAX 11000         // solve class 2: 6 + M <= SDSM_MAX_N_SOLVE and envelope <= 11000 doubles (LDS ~ 157 KB)
+#define SDSM_K1_DENSE_N 70         // 6 + M <= 70: even a dense triangle fits class 1
+#define SDSM_ENV_DENSE_N 146       // 6 + M <= 146: even a dense triangle fits class 2
 #define SDSM_ELL_GROUPS_REG 7       // groups of 4 G~ row entries the solve kernel keeps in registers (rows of <= 28 entries)
 #define SDSM_MAX_ELL_GROUPS 256    // zcap <= 1024 entries per row of G~ (a solvable candidate has M <= 1018 columns)
 #define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the largest solve class (Hessian + factor in global memory)
@@ -49,9 +53,9 @@ struct CandDesc {
     int32_t r0, c0, h, w;   // region bounding box (union of the atoms' valid extents)
     int32_t fp_off, fp_len; // footprint labels
     int32_t Mcap;       // upper bound of M
-    int32_t hsave_slot; // slot in the global Hessian-copy pool (only candidates that may reach the in-place class), else -1
+    int32_t hsave_slot; // unused (-1)
     uint32_t perm_inv;  // crop position of the pixel with raster rank i is (i * perm_inv) mod N (low-discrepancy scatter)
-    int32_t hglob_slot; // slot in the global Hessian + factor pool of the largest class (6 + Mcap > SDSM_MAX_N_LDS), else -1
+    int32_t hglob_slot; // slot in the global Hessian pool of the class whose envelope does not fit LDS (only possible if 6 + Mcap > SDSM_ENV_DENSE_N), else -1
     int32_t pad;
 };
 
@@ -64,7 +68,7 @@ struct CandState {
     int32_t zmax;       // largest number of non-zeros in a row of G~
     unsigned long long sum_r, sum_c, sum_rr, sum_cc;   // moments of the y > 0 pixels (image coordinates)
     int32_t hzmax;      // largest number of 'significant' entries (>= hess_thr * row maximum) in a row of G~
-    int32_t reserved;
+    int32_t env_size;   // doubles of the solver's Hessian in envelope storage (see env_fst / env_rb)
     int32_t gcount[8];  // gcount[j] = crop positions whose row has more than 4 j entries (positions are sorted by that)
 };
 static_assert(sizeof(CandState) == 96 && SDSM_ELL_GROUPS_REG <= 8, "CandState layout");
@@ -94,10 +98,13 @@ struct BatchParams {
     float *ell_w;
     uint16_t *ell_idx;
     uint32_t *ell_meta;                // entries of the row | entries used by the solver's approximate Hessian << 16
+    // Envelope of the solver's Hessian, unknowns ordered xi_0 .. xi_{M-1}, theta_0 .. theta_5: row a of the xi block
+    // stores columns env_fst[a] .. a (env_fst: smallest column any pixel couples a with, made non-decreasing in a and a
+    // multiple of 4), entry (a, b) at env_rb[a] + b; the 6 theta rows are dense and follow.  Indexed by xi_off + a.
+    int32_t *env_fst;
+    int32_t *env_rb;
     const float *psf;
-    double *hsave;                     // per-candidate Hessian copy for the in-place class
-    int64_t hsave_stride;
-    double *hglob;                     // per-candidate Hessian + factor of the global-memory class
+    double *hglob;                     // per-candidate Hessian of the global-memory class (envelope too large for LDS)
     int64_t hglob_stride;
     long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 8 cycle counters per candidate
 };

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     __shared__ int sh_M, sh_npos, sh_err;
     __shared__ int cls_cnt[SDSM_MAX_ELL_GROUPS + 1], cls_start[SDSM_MAX_ELL_GROUPS + 1], cls_run[SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int wave_cnt[SDSM_WAVES][SDSM_MAX_ELL_GROUPS + 1];
+    __shared__ int efirst[SDSM_MAX_N_SOLVE];             // envelope of the solver's Hessian: first coupled column per grid point
 
     const int tid = threadIdx.x;
     const int ci = P.order[blockIdx.x];
@@ -338,6 +339,9 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         }
     }
 
+    for (int j = tid; j < M; j += SDSM_WG) efirst[j] = j;
+    __syncthreads();
+
     // ---- 5. rows of G~: PSF gather, float32 pairwise row sum, float32 division (dsm.py:192-193) --
     bool bad = false;
     int zmax = 0, hzmax = 0;
@@ -384,6 +388,10 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
                 lo++; hi--;
             }
             hz = lo;
+            // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
+            int mn = 1 << 30;
+            for (int a = 0; a < hz; a++) { const int ia = P.ell_idx[ell_at(c.base, cd.N, a)]; mn = ia < mn ? ia : mn; }
+            for (int a = 0; a < hz; a++) atomicMin(&efirst[P.ell_idx[ell_at(c.base, cd.N, a)]], mn);
         }
         P.ell_meta[cd.crop_off + pos] = (uint32_t)c.nnz | ((uint32_t)hz << 16);
         zmax = c.nnz > zmax ? c.nnz : zmax;
@@ -393,6 +401,19 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     zmax = -block_min_i32(-zmax, scr32);
     hzmax = -block_min_i32(-hzmax, scr32);
     __syncthreads();
+    // ---- 6. envelope storage of the Hessian (BatchParams.env_fst / env_rb): first columns made non-decreasing and
+    //      multiples of 4 (the factorisation works on panels of 4 columns), row bases by a running sum ------------
+    if (tid == 0) {
+        int run = M;
+        for (int a = M - 1; a >= 0; a--) { run = efirst[a] < run ? efirst[a] : run; efirst[a] = run & ~3; }
+        int rp = 0;
+        for (int a = 0; a < M; a++) {
+            P.env_fst[cd.xi_off + a] = efirst[a];
+            P.env_rb[cd.xi_off + a] = rp - efirst[a];
+            rp += a - efirst[a] + 1;
+        }
+        s.env_size = rp + 6 * M + 21;
+    }
     s.M = M; s.zmax = zmax; s.hzmax = hzmax;
     for (int j = 0; j < 8; j++) {                        // positions [0, gcount[j]) have rows of more than 4 j entries
         int acc = 0;

@@ -45,17 +45,22 @@ namespace {
 #define HZREG 12         // leading ('significant') slots unrolled for the approximate Hessian
 
 // Compile-time LDS layout (offsets in doubles from the start of dynamic LDS).
-template <int NMAX, bool INPLACE, bool GLOBALH = false, int WGSIZE = 256>
+// The Hessian lives in ENVELOPE storage (BatchParams.env_fst / env_rb): unknowns ordered xi_0 .. xi_{M-1}, theta_0 ..
+// theta_5 ("logical" order i = 0 .. n-1), row i stores columns fst[i] .. i at rb[i] + column.  The xi block of the
+// thresholded Hessian is banded (a pixel couples only the few grid points around it), so the envelope is a fraction of
+// the dense triangle and the Cholesky factor (computed in place) fills only the envelope.
+template <int NMAX_, int EMAX_, bool GLOBALH = false, int WGSIZE = 256>
 struct Lay {
+    static constexpr int NMAX = NMAX_, EMAX = EMAX_;
     static constexpr int WGS = WGSIZE, NWAVES = WGSIZE / 64;
-    static constexpr bool GLOBAL_H = GLOBALH;      // Hessian and factor in global memory (largest class)
-    static constexpr int NP = GLOBALH ? 0 : NMAX * (NMAX + 1) / 2;
-    static constexpr int NPG = NMAX * (NMAX + 1) / 2;
-    static constexpr int W = NMAX + 2;    // vectors are indexed up to n (right-hand-side row) inclusive
+    static constexpr bool GLOBAL_H = GLOBALH;      // Hessian in global memory (envelope larger than LDS)
+    static constexpr int W = NMAX + 2;             // vectors are indexed up to n (right-hand-side row) inclusive
     static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
-    static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, HP = FLAG + 2;
-    static constexpr int LP = INPLACE ? HP : HP + NP;
-    static constexpr int END = LP + NP;
+    static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, IB = FLAG + 2;
+    static constexpr int NPANEL = NMAX / 4 + 2;
+    static constexpr int IB_DOUBLES = (2 * W + NPANEL + 1) / 2;      // int arrays: rb[W], fst[W], rend[NPANEL]
+    static constexpr int HP = IB + IB_DOUBLES;
+    static constexpr int END = HP + (GLOBALH ? 0 : EMAX);
     static constexpr int TOTAL_BYTES = ((END * 8 + 15) / 16) * 16;
 };
 
@@ -76,9 +81,8 @@ struct Cand {                       // per-candidate global pointers (already of
     g_cu16x4_p ell_i4;                  // (4 column indices)
     g_cu32_p ell_meta;                  // row entries | Hessian entries << 16
     int gcount[SDSM_ELL_GROUPS_REG];    // positions [0, gcount[j]) have rows of more than 4 j entries
-    g_double_p hsave;
-    double *hglob;                      // flat pointer: Hessian (NPG doubles) followed by the factor (NPG doubles)
-    int N, zmax, hzmax;
+    double *hglob;                      // flat pointer: Hessian of the global-memory class
+    int N, zmax, hzmax, env_size;
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
 };
@@ -86,7 +90,9 @@ struct Cand {                       // per-candidate global pointers (already of
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
 
 template <class L> __device__ __forceinline__ double *hess_ptr(const Cand &c) { if constexpr (L::GLOBAL_H) return c.hglob; else return SD + L::HP; }
-template <class L> __device__ __forceinline__ double *fact_ptr(const Cand &c) { if constexpr (L::GLOBAL_H) return c.hglob + L::NPG; else return SD + L::LP; }
+#define RBP ((int *)(SD + L::IB))              // rb[i]: entry (i, j) of the Hessian / factor is at rb[i] + j (logical order)
+#define FSTP (RBP + L::W)                      // fst[i]: first stored column of row i (0 for the theta rows)
+#define RENDP (FSTP + L::W)                    // rend[p]: last xi row that has entries in the columns of panel p
 
 // loss terms of one pixel given t = y * S     (dsm.py:298-300, 306-310, 319-322, 344, 361-366)
 __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, double *r, double *dcurv)
@@ -193,7 +199,7 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M)
         s2 += t2;
         g[6 + j] += c.alpha * (xi / t2);
         double gd = c.alpha * (1 / t2 - t3 / (t2 * t2 * t2));
-        Hp[tri(6 + j, 6 + j)] += gd < 0 ? 0 : gd;
+        Hp[RBP[j] + j] += gd < 0 ? 0 : gd;
     }
     s2 = block_sum<L::NWAVES>(s2, SD + L::RED);
     double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
@@ -257,11 +263,15 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
 {
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
-    const int n = 6 + M, np = n * (n + 1) / 2;
+    const int n = 6 + M;
     double *Hp = hess_ptr<L>(c), *g = SD + L::G;
     const double *xv = SD + L::X;
-    for (int e = tid; e < np; e += L::WGS) Hp[e] = 0;
+    const int *rbp = RBP;
+    for (int e = tid; e < c.env_size; e += L::WGS) Hp[e] = 0;
     for (int i = tid; i < n; i += L::WGS) g[i] = 0;
+    int rbt[6];                                          // the 6 dense theta rows (uniform)
+#pragma unroll
+    for (int b = 0; b < 6; b++) rbt[b] = __builtin_amdgcn_readfirstlane(rbp[M + b]);
     __syncthreads();
     double red[28];                                      // psi, g_theta[6], 6x6 lower triangle (21)
 #pragma unroll
@@ -308,44 +318,44 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
                 }
                 FINE_ADD(11);
                 if (c.hzmax <= HZREG) {
+                    int rbs[HZREG];                                                      // row bases of the leading entries
+#pragma unroll
+                    for (int a = 0; a < HZREG; a++) rbs[a] = a < hnz ? rbp[id[a]] : 0;
 #pragma unroll
                     for (int a = 0; a < HZREG; a++) {                                    // approximate Hessian: leading entries
                         if (a < hnz) {
                             const double dwa = dc * (double)w[a];
-                            const int ra = 6 + id[a];
-                            double *Hrow = Hp + tri(ra, 0);
+                            const int ia = id[a];
 #pragma unroll
-                            for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
+                            for (int b = 0; b < 6; b++) atomicAdd(&Hp[rbt[b] + ia], dwa * q[b]);      // theta rows, column xi_ia
 #pragma unroll
                             for (int b = 0; b <= a; b++) {
-                                const int rb = 6 + id[b];
-                                atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)w[b]);
+                                const int ib = id[b];
+                                atomicAdd(&Hp[ia >= ib ? rbs[a] + ib : rbs[b] + ia], dwa * (double)w[b]);
                             }
                         }
                     }
                 } else {
                     for (int a = 0; a < hnz; a++) {
                         const double dwa = dc * (double)ell_w_at(c, a, p);
-                        const int ra = 6 + ell_i_at(c, a, p);
-                        double *Hrow = Hp + tri(ra, 0);
-                        for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
+                        const int ia = ell_i_at(c, a, p);
+                        for (int b = 0; b < 6; b++) atomicAdd(&Hp[rbt[b] + ia], dwa * q[b]);
                         for (int b = 0; b <= a; b++) {
-                            const int rb = 6 + ell_i_at(c, b, p);
-                            atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)ell_w_at(c, b, p));
+                            const int ib = ell_i_at(c, b, p);
+                            atomicAdd(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa * (double)ell_w_at(c, b, p));
                         }
                     }
                 }
             } else {
                 for (int a = 0; a < nnz; a++) {
                     const double wa = (double)ell_w_at(c, a, p), dwa = dc * wa;
-                    const int ra = 6 + ell_i_at(c, a, p);
-                    atomicAdd(&g[ra], r * wa);
+                    const int ia = ell_i_at(c, a, p);
+                    atomicAdd(&g[6 + ia], r * wa);
                     if (a >= hnz) continue;
-                    double *Hrow = Hp + tri(ra, 0);
-                    for (int b = 0; b < 6; b++) atomicAdd(&Hrow[b], dwa * q[b]);
+                    for (int b = 0; b < 6; b++) atomicAdd(&Hp[rbt[b] + ia], dwa * q[b]);
                     for (int b = 0; b <= a; b++) {
-                        const int rb = 6 + ell_i_at(c, b, p);
-                        atomicAdd(&Hp[ra >= rb ? tri(ra, rb) : tri(rb, ra)], dwa * (double)ell_w_at(c, b, p));
+                        const int ib = ell_i_at(c, b, p);
+                        atomicAdd(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa * (double)ell_w_at(c, b, p));
                     }
                 }
             }
@@ -364,7 +374,9 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
         double hv = 0;
 #pragma unroll
         for (int e = 0; e < 21; e++) hv = tid == e ? red[7 + e] : hv;
-        Hp[tid] = hv;                                    // rows 0..5 of the packed triangle are its first 21 entries
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= tid) a++;
+        Hp[rbp[M + a] + M + (tid - a * (a + 1) / 2)] = hv;      // theta-theta block: columns M .. M + a of row M + a
     }
     __syncthreads();
     double psi = red[0];
@@ -375,42 +387,42 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Solve H d = -g with Jacobi scaling and an escalating diagonal shift (same schedule as the oracle).
-// Right-looking Cholesky of the scaled matrix, the right-hand side rides along as row n; all 256 threads update
-// the trailing sub-matrix of every column.  Returns false on numerical failure.  *lam2 = -g.d (unscaled).
-// INPLACE: the factor overwrites the Hessian; a copy is kept in global memory (c.hsave) for retries.
+// Solve (H + tau D) d = -g, D = diag(H): Jacobi scaling, then a blocked right-looking Cholesky IN PLACE on the envelope
+// (panels of NB = 4 columns, the right-hand side rides along as row n), then blocked back substitution.
+// A panel only touches the rows whose envelope reaches its columns (xi rows up to rend[panel], the 6 theta rows and
+// the right-hand side): about (bandwidth + 7)^2 / 2 entries per panel instead of the whole trailing triangle.
+// Returns 0 ok, 1 not positive definite (the Hessian is destroyed: re-evaluate and retry with a larger shift),
+// 2 non-finite input.  *lam2 = -g.d.
 // ---------------------------------------------------------------------------------------------------------
-template <class L, bool INPLACE>
-__device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
+template <class L>
+__device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, double *lam2)
 {
     const int tid = threadIdx.x;
-    const int np = n * (n + 1) / 2;
-    double *Hp = hess_ptr<L>(c), *Lp = fact_ptr<L>(c), *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *colj = SD + L::XT;   // XT is free between line searches
+    const int n = 6 + M;
+    double *Hp = hess_ptr<L>(c), *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *zl = SD + L::XT;   // XT is free between line searches
+    const int *rbp = RBP, *fstp = FSTP, *rendp = RENDP;
     int *flag = (int *)(SD + L::FLAG);
     bool finite = true;
+    // logical order i: xi_0 .. xi_{M-1}, theta_0 .. theta_5 (sc, yrow, dg, zl); variable order (x, g, d): theta first
     for (int i = tid; i < n; i += L::WGS) {
-        double hii = Hp[tri(i, i)];
+        double hii = M > 0 ? Hp[rbp[i] + i] : Hp[tri(i, i)];
         if (!(hii > 0) || !isfinite(hii)) hii = 1;
         sc[i] = 1 / sqrt(hii);
         if (!isfinite(g[i])) finite = false;
     }
-    for (int e = tid; e < np; e += L::WGS) {
-        double v = Hp[e];
-        if (!isfinite(v)) finite = false;
-        if (INPLACE) c.hsave[e] = v;
-    }
+    for (int e = tid; e < c.env_size; e += L::WGS) if (!isfinite(Hp[e])) finite = false;
     if (tid == 0) *flag = 0;
     __syncthreads();
     if (!finite) *flag = 1;
     __syncthreads();
-    if (*flag) return false;
+    if (*flag) return 2;
 
-    if (n == 6) {
+    if (M == 0) {
         // ---- elliptical model: 6 x 6 system solved redundantly by every thread in registers (no barriers) ----
         double A[6][6], bb[6], s6[6], z[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) s6[i] = sc[i];
-        double tau = 0;
+        double tau = tau_in;
         bool ok = false;
         for (int attempt = 0; attempt < 12 && !ok; attempt++) {
             ok = true;
@@ -442,7 +454,7 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
             }
             if (!ok) tau = tau == 0 ? 1e-12 : tau * 100;
         }
-        if (!ok) return false;
+        if (!ok) return 2;
         double l2 = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) l2 += z[i] * z[i];
@@ -456,112 +468,113 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
         bool fin = isfinite(l2);
 #pragma unroll
         for (int i = 0; i < 6; i++) { z[i] *= s6[i]; if (!isfinite(z[i])) fin = false; }
-        if (!fin) return false;                                   // uniform: every thread computed the same values
+        if (!fin) return 2;                                       // uniform: every thread computed the same values
         if (tid < 6) d[tid] = z[tid];
         __syncthreads();
         *lam2 = l2;
-        return true;
+        return 0;
     }
 
-    // ---- general case: blocked right-looking Cholesky, panels of NB = 4 columns, 2 workgroup barriers per PANEL.
-    //      Every thread factors the panel's 4x4 diagonal block redundantly in registers; one thread per row solves its
-    //      4 panel entries against it; then all 256 threads (16 x 16 grid) apply the rank-4 update to the trailing
-    //      sub-matrix.  The right-hand side rides along as row n.
     constexpr int NB = 4;
-    constexpr int GR = L::WGS / 16;                             // thread grid GR x 16 over the trailing sub-matrix
+    constexpr int GR = L::WGS / 16;                             // thread grid GR x 16 over the active rows x columns
     const int ri = tid >> 4, ki = tid & 15;
-    double tau = 0;
-    bool ok = false;
-    for (int attempt = 0; attempt < 12 && !ok; attempt++) {
-        for (int i = ri; i < n; i += GR) {                        // scaled copy
-            const double si = sc[i];
-            for (int k = ki; k <= i; k += 16) {
-                double v = (INPLACE ? c.hsave[tri(i, k)] : Hp[tri(i, k)]) * si * sc[k];
-                if (i == k) v += tau;
-                Lp[tri(i, k)] = v;
+    const double *scl = sc;
+    for (int i = ri; i < n; i += GR) {                          // scale in place, shift the diagonal
+        const double si = scl[i];
+        double *row = Hp + rbp[i];
+        for (int k = fstp[i] + ki; k <= i; k += 16) {
+            double v = row[k] * si * scl[k];
+            if (i == k) v += tau_in;
+            row[k] = v;
+        }
+    }
+    for (int i = tid; i < n; i += L::WGS) { const int vi = i < M ? 6 + i : i - M; yrow[i] = -g[vi] * scl[i]; }
+    __syncthreads();
+    bool ok = true;
+    for (int j0 = 0; j0 < n; j0 += NB) {
+        const int nb = n - j0 < NB ? n - j0 : NB;
+        // 1. diagonal block, redundantly in registers (rows j0 .. j0+3 all store column j0: fst is a multiple of 4)
+        double t[NB][NB];
+#pragma unroll
+        for (int a2 = 0; a2 < NB; a2++)
+#pragma unroll
+            for (int b2 = 0; b2 <= a2; b2++) t[a2][b2] = a2 < nb ? Hp[rbp[j0 + a2] + j0 + b2] : (a2 == b2 ? 1.0 : 0.0);
+#pragma unroll
+        for (int cc = 0; cc < NB; cc++) {
+            double piv = t[cc][cc];
+#pragma unroll
+            for (int m = 0; m < cc; m++) piv -= t[cc][m] * t[cc][m];
+            if (cc < nb && (!(piv > 1e-300) || !isfinite(piv))) { ok = false; piv = 1; }
+            const double l = sqrt(piv);
+            t[cc][cc] = l;
+#pragma unroll
+            for (int a2 = cc + 1; a2 < NB; a2++) {
+                double v = t[a2][cc];
+#pragma unroll
+                for (int m = 0; m < cc; m++) v -= t[a2][m] * t[cc][m];
+                t[a2][cc] = v / l;
             }
         }
-        for (int k = tid; k < n; k += L::WGS) yrow[k] = -g[k] * sc[k];
-        __syncthreads();
-        ok = true;
-        for (int j0 = 0; j0 < n; j0 += NB) {
-            const int nb = n - j0 < NB ? n - j0 : NB;
-            // 1. diagonal block, redundantly in registers
-            double t[NB][NB];
+        if (!ok) break;                                        // uniform: every thread computed the same block
+        __syncthreads();                                       // everybody has read the block before it is overwritten
+        if (tid < NB * NB) {                                   // factored block back
+            const int a2 = tid / NB, b2 = tid % NB;
+            if (b2 <= a2 && a2 < nb) {
+                double v = 0;
 #pragma unroll
-            for (int a2 = 0; a2 < NB; a2++)
+                for (int x2 = 0; x2 < NB; x2++)
 #pragma unroll
-                for (int b2 = 0; b2 <= a2; b2++) t[a2][b2] = a2 < nb ? Lp[tri(j0 + a2, j0 + b2)] : (a2 == b2 ? 1.0 : 0.0);
+                    for (int y2 = 0; y2 <= x2; y2++) v = (x2 == a2 && y2 == b2) ? t[x2][y2] : v;
+                Hp[rbp[j0 + a2] + j0 + b2] = v;
+                if (a2 == b2) dg[j0 + a2] = v;
+            }
+        }
+        // active rows below the panel: xi rows jn .. re, theta rows, right-hand side (compact index t -> logical row)
+        const int jn = j0 + nb;
+        const int re = j0 < M ? rendp[j0 >> 2] : M - 1;
+        const int nxi = jn < M && re >= jn ? re - jn + 1 : 0;
+        const int th0 = jn > M ? jn : M;
+        const int na = nxi + (n - th0) + 1;
+        // 2. panel entries of the active rows: one thread per row, triangular solve against the block
+        for (int tt = tid; tt < na; tt += L::WGS) {
+            const int i = tt < nxi ? jn + tt : th0 + (tt - nxi);          // == n for the right-hand side
+            double *row = i < n ? Hp + rbp[i] + j0 : yrow + j0;
+            double v[NB];
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++) v[cc] = cc < nb ? row[cc] : 0.0;
 #pragma unroll
             for (int cc = 0; cc < NB; cc++) {
-                double piv = t[cc][cc];
+                double acc = v[cc];
 #pragma unroll
-                for (int m = 0; m < cc; m++) piv -= t[cc][m] * t[cc][m];
-                if (cc < nb && (!(piv > 1e-300) || !isfinite(piv))) { ok = false; piv = 1; }
-                const double l = sqrt(piv);
-                t[cc][cc] = l;
-#pragma unroll
-                for (int a2 = cc + 1; a2 < NB; a2++) {
-                    double v = t[a2][cc];
-#pragma unroll
-                    for (int m = 0; m < cc; m++) v -= t[a2][m] * t[cc][m];
-                    t[a2][cc] = v / l;
-                }
+                for (int m = 0; m < cc; m++) acc -= v[m] * t[cc][m];
+                v[cc] = acc / t[cc][cc];
             }
-            if (!ok) break;                                        // uniform: every thread computed the same block
-            __syncthreads();                                       // everybody has read the block before it is overwritten
-            if (tid < NB * NB) {                                   // factored block back to LDS
-                const int a2 = tid / NB, b2 = tid % NB;
-                if (b2 <= a2 && a2 < nb) {
-                    double v = 0;
 #pragma unroll
-                    for (int x2 = 0; x2 < NB; x2++)
-#pragma unroll
-                        for (int y2 = 0; y2 <= x2; y2++) v = (x2 == a2 && y2 == b2) ? t[x2][y2] : v;
-                    Lp[tri(j0 + a2, j0 + b2)] = v;
-                    if (a2 == b2) dg[j0 + a2] = v;
-                }
-            }
-            // 2. panel rows below the block: one thread per row, triangular solve against the block
-            for (int i = j0 + nb + tid; i <= n; i += L::WGS) {
-                double *row = i < n ? Lp + tri(i, j0) : yrow + j0;
-                double v[NB];
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) v[cc] = cc < nb ? row[cc] : 0.0;
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) {
-                    double acc = v[cc];
-#pragma unroll
-                    for (int m = 0; m < cc; m++) acc -= v[m] * t[cc][m];
-                    v[cc] = acc / t[cc][cc];
-                }
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) if (cc < nb) row[cc] = v[cc];
-            }
-            __syncthreads();
-            // 3. rank-nb update of the trailing sub-matrix (rows / columns >= j0 + nb; row n = right-hand side)
-            const int jn = j0 + nb;
-            for (int i = jn + ri; i <= n; i += GR) {
-                const double *pi = i < n ? Lp + tri(i, j0) : yrow + j0;
-                double li[NB];
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) li[cc] = cc < nb ? pi[cc] : 0.0;
-                double *Li = i < n ? Lp + tri(i, 0) : yrow;
-                const int kend = i < n ? i : n - 1;
-                for (int k = jn + ki; k <= kend; k += 16) {
-                    const double *pk = Lp + tri(k, j0);
-                    double acc = Li[k];
-#pragma unroll
-                    for (int cc = 0; cc < NB; cc++) acc -= li[cc] * (cc < nb ? pk[cc] : 0.0);
-                    Li[k] = acc;
-                }
-            }
-            __syncthreads();
+            for (int cc = 0; cc < NB; cc++) if (cc < nb) row[cc] = v[cc];
         }
         __syncthreads();
-        if (!ok) tau = tau == 0 ? 1e-12 : tau * 100;
+        // 3. rank-nb update of the active rows x active columns
+        for (int ti = ri; ti < na; ti += GR) {
+            const int i = ti < nxi ? jn + ti : th0 + (ti - nxi);
+            const double *pi = i < n ? Hp + rbp[i] + j0 : yrow + j0;
+            double li[NB];
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++) li[cc] = cc < nb ? pi[cc] : 0.0;
+            double *Li = i < n ? Hp + rbp[i] : yrow;
+            const int tkend = ti < na - 1 ? ti : na - 2;                  // columns: active rows except the right-hand side
+            for (int tk = ki; tk <= tkend; tk += 16) {
+                const int k = tk < nxi ? jn + tk : th0 + (tk - nxi);
+                const double *pk = Hp + rbp[k] + j0;
+                double acc = Li[k];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) acc -= li[cc] * (cc < nb ? pk[cc] : 0.0);
+                Li[k] = acc;
+            }
+        }
+        __syncthreads();
     }
-    if (!ok) return false;
+    __syncthreads();
+    if (!ok) return 1;
     double l2 = 0;
     for (int i = tid; i < n; i += L::WGS) l2 += yrow[i] * yrow[i];
     l2 = block_sum<L::NWAVES>(l2, SD + L::RED);
@@ -573,35 +586,44 @@ __device__ __noinline__ bool factor_solve(const Cand &c, int n, double *lam2)
         for (int cc = NB - 1; cc >= 0; cc--) {
             double acc = cc < nb ? yrow[j0 + cc] : 0.0;
 #pragma unroll
-            for (int m = cc + 1; m < NB; m++) if (m < nb) acc -= Lp[tri(j0 + m, j0 + cc)] * z[m];
+            for (int m = cc + 1; m < NB; m++) if (m < nb) acc -= Hp[rbp[j0 + m] + j0 + cc] * z[m];
             z[cc] = cc < nb ? acc / dg[j0 + cc] : 0.0;
         }
         if (tid < NB && tid < nb) {
             double v = 0;
 #pragma unroll
             for (int x2 = 0; x2 < NB; x2++) v = x2 == tid ? z[x2] : v;
-            d[j0 + tid] = v;
+            zl[j0 + tid] = v;
         }
-        for (int i = tid; i < j0; i += L::WGS) {
+        int f4[NB];
+#pragma unroll
+        for (int cc = 0; cc < NB; cc++) f4[cc] = cc < nb ? fstp[j0 + cc] : j0;
+        const int start = j0 + nb - 1 >= M ? 0 : f4[0];          // fst is non-decreasing over the xi rows, 0 for theta rows
+        for (int i = start + tid; i < j0; i += L::WGS) {
             double acc = yrow[i];
 #pragma unroll
-            for (int cc = 0; cc < NB; cc++) if (cc < nb) acc -= Lp[tri(j0 + cc, i)] * z[cc];
+            for (int cc = 0; cc < NB; cc++) if (cc < nb && i >= f4[cc]) acc -= Hp[rbp[j0 + cc] + i] * z[cc];
             yrow[i] = acc;
         }
         __syncthreads();
     }
     bool fin = isfinite(l2);
-    for (int i = tid; i < n; i += L::WGS) { d[i] *= sc[i]; if (!isfinite(d[i])) fin = false; }
+    for (int i = tid; i < n; i += L::WGS) {
+        const int vi = i < M ? 6 + i : i - M;
+        const double dv = zl[i] * sc[i];
+        d[vi] = dv;
+        if (!isfinite(dv)) fin = false;
+    }
     if (!fin) *flag = 1;
     __syncthreads();
-    if (*flag) return false;
+    if (*flag) return 2;
     *lam2 = l2;
-    return true;
+    return 0;
 }
 
 // Damped Newton on f = scale * psi from the parameters at L::X (in/out).
 // Returns 0 optimal, 1 unknown (iteration cap / stalled line search), 2 numerical failure.
-template <class L, bool INPLACE>
+template <class L>
 __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, double *psi_out, int *iters_out, int *ev_value, int *ev_full PROF_PARAM)
 {
     const int tid = threadIdx.x, n = 6 + M;
@@ -617,8 +639,14 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         double f = c.scale * psi;
         if (iters >= max_iters) { status = 1; break; }
         if (!isfinite(f)) { status = 2; break; }
-        double lam2u;
-        if (!factor_solve<L, INPLACE>(c, n, &lam2u)) { status = 2; break; }
+        double lam2u, tau = 0;
+        int fs = factor_solve<L>(c, M, tau, &lam2u);
+        for (int attempt = 1; fs == 1 && attempt < 12; attempt++) {      // escalating diagonal shift (same schedule as the oracle)
+            tau = tau == 0 ? 1e-12 : tau * 100;
+            eval_full_sparse<L>(c, M PROF_ARG);                            // the failed factorisation overwrote the Hessian
+            fs = factor_solve<L>(c, M, tau, &lam2u);
+        }
+        if (fs != 0) { status = 2; break; }
         double lam2 = c.scale * lam2u;
         iters++;
         PROF_ADD(3, pt);
@@ -675,14 +703,14 @@ __device__ __forceinline__ void reparam(const double *th, double p0, double p1, 
 
 }  // namespace
 
-// NMAX: largest 6 + M this instantiation handles; candidates with 6 + M in (nmin_excl, NMAX] are processed,
-// the others are left to the other classes.  The smallest class also writes the records of trivial /
-// failed-setup candidates.
-template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false, int WGSIZE = 256>
-__global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int nmin_excl, int handles_rest, sdsm_record *records,
+// A candidate belongs to the FIRST class whose limits (6 + M <= NMAX and Hessian envelope <= EMAX doubles) it meets; the
+// limits of the previous class are passed at run time (nprev = 0 for the first class).  The first class also writes the
+// records of trivial / failed-setup candidates.
+template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256>
+__global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int nprev, int eprev, int handles_rest, sdsm_record *records,
                                                               uint32_t *masks, double *xi_out)
 {
-    using L = Lay<NMAX, INPLACE, GLOBALH, WGSIZE>;
+    using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
     const int tid = threadIdx.x;
     const int ci = P.order[blockIdx.x];
     const CandDesc cd = P.cand[ci];
@@ -702,19 +730,20 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     bool unsupported = false;
     if (6 + Mfull > SDSM_MAX_N_SOLVE) { unsupported = true; Mfull = 0; }     // elliptical result only (flagged)
     const int nfull = 6 + Mfull;
-    if (!(nfull > nmin_excl && nfull <= NMAX)) return;
-    if (GLOBALH && cd.hglob_slot < 0) {                          // cannot happen (M <= Mcap); never touch a missing slot
+    const int efull = Mfull > 0 ? st.env_size : 21;
+    if (nfull <= nprev && efull <= eprev) return;                // an earlier class took it
+    if (!(nfull <= NMAX && efull <= EMAX)) return;               // a later class takes it
+    if (GLOBALH && cd.hglob_slot < 0) {                          // cannot happen (the host reserves a slot whenever Mcap admits it)
         if (tid == 0) { sdsm_record r0 = {}; r0.status = SDSM_CAND_UNSUPPORTED; r0.n_pixels = cd.N; r0.n_deform = st.M; *rec = r0; }
         return;
     }
 
     Cand c;
-    c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0; c.hzmax = Mfull > 0 ? st.hzmax : 0;
+    c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0; c.hzmax = Mfull > 0 ? st.hzmax : 0; c.env_size = 21;
     c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
     c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = Mfull > 0 ? st.gcount[j] : 0;
-    c.hsave = (g_double_p)((INPLACE && cd.hsave_slot >= 0) ? P.hsave + (int64_t)cd.hsave_slot * P.hsave_stride : nullptr);
     c.hglob = (GLOBALH && cd.hglob_slot >= 0) ? P.hglob + (int64_t)cd.hglob_slot * P.hglob_stride : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
     c.epsilon = P.epsilon; c.alpha = P.alpha;
@@ -775,10 +804,23 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
             M = Mfull;
             __syncthreads();
             for (int i = tid; i < NMAX; i += L::WGS) x[i] = i < 6 ? keep[i] : 0;
+            if (M > 0) {                                                         // envelope of the Hessian (setup kernel)
+                int *rbp = RBP, *fstp = FSTP, *rendp = RENDP;
+                const int exi = efull - 6 * M - 21;
+                for (int a = tid; a < M; a += L::WGS) { rbp[a] = P.env_rb[cd.xi_off + a]; fstp[a] = P.env_fst[cd.xi_off + a]; }
+                if (tid < 6) { rbp[M + tid] = exi + tid * M + tid * (tid + 1) / 2; fstp[M + tid] = 0; }
+                __syncthreads();
+                for (int pnl = tid; 4 * pnl < M; pnl += L::WGS) {                // last xi row whose envelope reaches column 4 pnl
+                    int lo = 4 * pnl, hi = M - 1;                                // fst is non-decreasing, fst[4 pnl] <= 4 pnl
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (fstp[mid] <= 4 * pnl) lo = mid; else hi = mid - 1; }
+                    rendp[pnl] = lo;
+                }
+                c.env_size = efull;
+            }
             __syncthreads();
         }
         double psi; int its;
-        int s = newton<L, INPLACE>(c, M, P.max_iters, &psi, &its, &ev_value, &ev_full PROF_ARG);
+        int s = newton<L>(c, M, P.max_iters, &psi, &its, &ev_value, &ev_full PROF_ARG);
 #ifdef SDSM_PROFILE
         if (phase < 2) { prof_acc[6] = PROF_NOW() - prof_t_start; }
 #endif
@@ -871,20 +913,20 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 }
 
 // ---- launch helper (called from sdsm_api.hip) ----------------------------------------------------
-// class AB: n <= 84   256 threads, separate factor     LDS ~ 63 KB   (2 workgroups / CU, register bound)
-// class C:  n <= 172  512 threads, in-place factor     LDS ~ 130 KB  (1 workgroup / CU)
-// class D:  n <= 1024 512 threads, Hessian + factor in global memory (slow path, only launched when needed)
+// class 1: 6 + M <= 128, envelope <= 2560 doubles   256 threads, LDS ~ 30 KB  (register bound: 2 workgroups / CU)
+// class 2: 6 + M <= 1024, envelope <= 11000 doubles 512 threads, LDS ~ 157 KB (1 workgroup / CU)
+// class 3: 6 + M <= 1024, any envelope              512 threads, Hessian in global memory (only launched when needed)
 // The classes are independent: they run concurrently on streams forked from the caller's stream.
-template <int NMAX, bool INPLACE, int WPE, bool GLOBALH = false, int WGSIZE = 256>
-static hipError_t launch_class(const BatchParams &P, int nmin_excl, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
+template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256>
+static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
-    auto kern = sdsm_k_solve<NMAX, INPLACE, WPE, GLOBALH, WGSIZE>;
-    constexpr int lds = Lay<NMAX, INPLACE, GLOBALH, WGSIZE>::TOTAL_BYTES;
+    auto kern = sdsm_k_solve<NMAX, EMAX, WPE, GLOBALH, WGSIZE>;
+    constexpr int lds = Lay<NMAX, EMAX, GLOBALH, WGSIZE>::TOTAL_BYTES;
     static_assert(lds <= 160 * 1024 - 512, "LDS budget");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     if (P.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nmin_excl, handles_rest, records, masks, xi_out);
+    hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nprev, eprev, handles_rest, records, masks, xi_out);
     return hipGetLastError();
 }
 
@@ -894,26 +936,23 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
 {
     (void)side2;
     hipError_t e;
-    // launch lists: P.order = [all n | the n_c candidates whose bound Mcap admits 6 + M > 84 | the n_d that admit > 172]
+    // launch lists: P.order = [all n | the n_c candidates whose bound Mcap admits more than class 1 | the n_d that admit more than class 2]
     BatchParams Pc = P, Pd = P;
     Pc.order = P.order + P.n; Pc.n = n_c;
     Pd.order = P.order + P.n + n_c; Pd.n = n_d;
     // fork: the side streams wait for everything queued on the caller's stream so far (setup kernel)
     if (n_c > 0 || n_d > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
-    if (n_d > 0) {   // 6 + M > 172: Hessian and factor in global memory (slow path)
+    if (n_d > 0) {
         if ((e = hipStreamWaitEvent(side3, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_MAX_N_SOLVE, false, 2, true, 512>(Pd, SDSM_MAX_N_LDS, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[3], side3)) != hipSuccess) return e;
     }
     if (n_c > 0) {
         if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<172, true, 2, false, 512>(Pc, 84, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512>(Pc, SDSM_K1_NMAX, SDSM_K1_EMAX, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
     }
-    // 6 + M <= 84 in ONE launch on the caller's stream: the small sizes (<= 40) would not gain occupancy from a smaller LDS
-    // footprint (register bound at 2 workgroups / CU either way), and one stream less per batch means more batches fit
-    // the hardware queues
-    if ((e = launch_class<84, false, 2>(P, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
+    if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 2>(P, 0, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
     if (n_d > 0 && (e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
     if (n_c > 0 && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
