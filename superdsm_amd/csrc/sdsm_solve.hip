@@ -386,6 +386,18 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
     return psi;
 }
 
+// 1 / sqrt(x) to double precision: hardware estimate + two Newton steps (x in the normal range)
+__device__ __forceinline__ double rsqrt_f64(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Solve (H + tau D) d = -g, D = diag(H): Jacobi scaling, then a blocked right-looking Cholesky IN PLACE on the envelope
 // (panels of NB = 4 columns, the right-hand side rides along as row n), then blocked back substitution.
@@ -402,20 +414,23 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
     double *Hp = hess_ptr<L>(c), *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *zl = SD + L::XT;   // XT is free between line searches
     const int *rbp = RBP, *fstp = FSTP, *rendp = RENDP;
     int *flag = (int *)(SD + L::FLAG);
-    bool finite = true;
-    // logical order i: xi_0 .. xi_{M-1}, theta_0 .. theta_5 (sc, yrow, dg, zl); variable order (x, g, d): theta first
-    for (int i = tid; i < n; i += L::WGS) {
-        double hii = M > 0 ? Hp[rbp[i] + i] : Hp[tri(i, i)];
-        if (!(hii > 0) || !isfinite(hii)) hii = 1;
-        sc[i] = 1 / sqrt(hii);
-        if (!isfinite(g[i])) finite = false;
-    }
-    for (int e = tid; e < c.env_size; e += L::WGS) if (!isfinite(Hp[e])) finite = false;
     if (tid == 0) *flag = 0;
+    // logical order i: xi_0 .. xi_{M-1}, theta_0 .. theta_5 (yrow, dg, zl); variable order (x, g, d): theta first
+    if (M == 0) {
+        bool finite = true;
+        for (int i = tid; i < 6; i += L::WGS) {
+            double hii = Hp[tri(i, i)];
+            if (!(hii > 0) || !isfinite(hii)) hii = 1;
+            sc[i] = 1 / sqrt(hii);
+            if (!isfinite(g[i])) finite = false;
+        }
+        for (int e = tid; e < 21; e += L::WGS) if (!isfinite(Hp[e])) finite = false;
+        __syncthreads();
+        if (!finite) *flag = 1;
+        __syncthreads();
+        if (*flag) return 2;
+    }
     __syncthreads();
-    if (!finite) *flag = 1;
-    __syncthreads();
-    if (*flag) return 2;
 
     if (M == 0) {
         // ---- elliptical model: 6 x 6 system solved redundantly by every thread in registers (no barriers) ----
@@ -475,26 +490,26 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
         return 0;
     }
 
+    // ---- general case.  No explicit Jacobi scaling: the Cholesky factor of D^-1/2 H D^-1/2 is D^-1/2 times the factor
+    //      of H, so pivots fail together and lam2 is the same; the shift tau * diag(H) is applied to the diagonal directly.
+    //      ONE workgroup barrier per panel: every thread factors the panel's 4x4 diagonal block redundantly in registers
+    //      (reciprocal square roots, no divisions), reads the RAW panel entries of the rows / columns it updates, solves
+    //      them against the block in registers and applies the rank-4 update; the factored block and the solved panel
+    //      entries are written after the barrier (nobody reads those columns again before the back substitution).
     constexpr int NB = 4;
     constexpr int GR = L::WGS / 16;                             // thread grid GR x 16 over the active rows x columns
     const int ri = tid >> 4, ki = tid & 15;
-    const double *scl = sc;
-    for (int i = ri; i < n; i += GR) {                          // scale in place, shift the diagonal
-        const double si = scl[i];
-        double *row = Hp + rbp[i];
-        for (int k = fstp[i] + ki; k <= i; k += 16) {
-            double v = row[k] * si * scl[k];
-            if (i == k) v += tau_in;
-            row[k] = v;
-        }
+    for (int i = tid; i < n; i += L::WGS) {
+        const int vi = i < M ? 6 + i : i - M;
+        yrow[i] = -g[vi];
+        if (tau_in > 0) Hp[rbp[i] + i] *= 1 + tau_in;
     }
-    for (int i = tid; i < n; i += L::WGS) { const int vi = i < M ? 6 + i : i - M; yrow[i] = -g[vi] * scl[i]; }
     __syncthreads();
-    bool ok = true;
+    bool ok = true, nonfinite = false;
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = n - j0 < NB ? n - j0 : NB;
-        // 1. diagonal block, redundantly in registers (rows j0 .. j0+3 all store column j0: fst is a multiple of 4)
-        double t[NB][NB];
+        // A. diagonal block (rows j0 .. j0+3 all store column j0: fst is a multiple of 4)
+        double t[NB][NB], rinv[NB];
 #pragma unroll
         for (int a2 = 0; a2 < NB; a2++)
 #pragma unroll
@@ -504,40 +519,78 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
             double piv = t[cc][cc];
 #pragma unroll
             for (int m = 0; m < cc; m++) piv -= t[cc][m] * t[cc][m];
-            if (cc < nb && (!(piv > 1e-300) || !isfinite(piv))) { ok = false; piv = 1; }
-            const double l = sqrt(piv);
-            t[cc][cc] = l;
+            if (cc < nb && !(piv > 0 && piv < 1.7e308)) { ok = false; if (!(piv <= 0)) nonfinite = true; piv = 1; }
+            const double r = rsqrt_f64(piv);
+            t[cc][cc] = piv * r;
+            rinv[cc] = r;
 #pragma unroll
             for (int a2 = cc + 1; a2 < NB; a2++) {
                 double v = t[a2][cc];
 #pragma unroll
                 for (int m = 0; m < cc; m++) v -= t[a2][m] * t[cc][m];
-                t[a2][cc] = v / l;
+                t[a2][cc] = v * r;
             }
         }
         if (!ok) break;                                        // uniform: every thread computed the same block
-        __syncthreads();                                       // everybody has read the block before it is overwritten
-        if (tid < NB * NB) {                                   // factored block back
-            const int a2 = tid / NB, b2 = tid % NB;
-            if (b2 <= a2 && a2 < nb) {
-                double v = 0;
-#pragma unroll
-                for (int x2 = 0; x2 < NB; x2++)
-#pragma unroll
-                    for (int y2 = 0; y2 <= x2; y2++) v = (x2 == a2 && y2 == b2) ? t[x2][y2] : v;
-                Hp[rbp[j0 + a2] + j0 + b2] = v;
-                if (a2 == b2) dg[j0 + a2] = v;
-            }
-        }
-        // active rows below the panel: xi rows jn .. re, theta rows, right-hand side (compact index t -> logical row)
+        // active rows below the panel: xi rows jn .. re, theta rows, right-hand side (compact index -> logical row)
         const int jn = j0 + nb;
         const int re = j0 < M ? rendp[j0 >> 2] : M - 1;
         const int nxi = jn < M && re >= jn ? re - jn + 1 : 0;
         const int th0 = jn > M ? jn : M;
         const int na = nxi + (n - th0) + 1;
-        // 2. panel entries of the active rows: one thread per row, triangular solve against the block
+        // B. rank-nb update of the active rows x active columns from the raw panel entries
+        for (int ti = ri; ti < na; ti += GR) {
+            const int i = ti < nxi ? jn + ti : th0 + (ti - nxi);          // == n for the right-hand side
+            const double *pi = i < n ? Hp + rbp[i] + j0 : yrow + j0;
+            double li[NB];
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++) li[cc] = cc < nb ? pi[cc] : 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++) {
+                double acc = li[cc];
+#pragma unroll
+                for (int m = 0; m < cc; m++) acc -= li[m] * t[cc][m];
+                li[cc] = acc * rinv[cc];
+            }
+            double *Li = i < n ? Hp + rbp[i] : yrow;
+            const int tkend = ti < na - 1 ? ti : na - 2;                  // columns: active rows except the right-hand side
+            for (int tk = ki; tk <= tkend; tk += 16) {
+                const int k = tk < nxi ? jn + tk : th0 + (tk - nxi);
+                const double *pk = Hp + rbp[k] + j0;
+                double lk[NB];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) lk[cc] = cc < nb ? pk[cc] : 0.0;
+                double acc = Li[k];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) {
+                    double a3 = lk[cc];
+#pragma unroll
+                    for (int m = 0; m < cc; m++) a3 -= lk[m] * t[cc][m];
+                    lk[cc] = a3 * rinv[cc];
+                    acc -= li[cc] * lk[cc];
+                }
+                Li[k] = acc;
+            }
+        }
+        __syncthreads();
+        // C. factored block, reciprocal diagonal and solved panel entries (columns j0 .. j0+3: not read again before
+        //    the back substitution, so the next panel starts without another barrier)
+        if (tid < NB * NB) {
+            const int a2 = tid / NB, b2 = tid % NB;
+            if (b2 <= a2 && a2 < nb) {
+                double v = 0, rv = 0;
+#pragma unroll
+                for (int x2 = 0; x2 < NB; x2++) {
+                    rv = x2 == a2 ? rinv[x2] : rv;
+#pragma unroll
+                    for (int y2 = 0; y2 <= x2; y2++) v = (x2 == a2 && y2 == b2) ? t[x2][y2] : v;
+                }
+                Hp[rbp[j0 + a2] + j0 + b2] = v;
+                if (a2 == b2) dg[j0 + a2] = rv;
+            }
+        }
         for (int tt = tid; tt < na; tt += L::WGS) {
-            const int i = tt < nxi ? jn + tt : th0 + (tt - nxi);          // == n for the right-hand side
+            const int i = tt < nxi ? jn + tt : th0 + (tt - nxi);
             double *row = i < n ? Hp + rbp[i] + j0 : yrow + j0;
             double v[NB];
 #pragma unroll
@@ -547,34 +600,14 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
                 double acc = v[cc];
 #pragma unroll
                 for (int m = 0; m < cc; m++) acc -= v[m] * t[cc][m];
-                v[cc] = acc / t[cc][cc];
+                v[cc] = acc * rinv[cc];
             }
 #pragma unroll
             for (int cc = 0; cc < NB; cc++) if (cc < nb) row[cc] = v[cc];
         }
-        __syncthreads();
-        // 3. rank-nb update of the active rows x active columns
-        for (int ti = ri; ti < na; ti += GR) {
-            const int i = ti < nxi ? jn + ti : th0 + (ti - nxi);
-            const double *pi = i < n ? Hp + rbp[i] + j0 : yrow + j0;
-            double li[NB];
-#pragma unroll
-            for (int cc = 0; cc < NB; cc++) li[cc] = cc < nb ? pi[cc] : 0.0;
-            double *Li = i < n ? Hp + rbp[i] : yrow;
-            const int tkend = ti < na - 1 ? ti : na - 2;                  // columns: active rows except the right-hand side
-            for (int tk = ki; tk <= tkend; tk += 16) {
-                const int k = tk < nxi ? jn + tk : th0 + (tk - nxi);
-                const double *pk = Hp + rbp[k] + j0;
-                double acc = Li[k];
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) acc -= li[cc] * (cc < nb ? pk[cc] : 0.0);
-                Li[k] = acc;
-            }
-        }
-        __syncthreads();
     }
     __syncthreads();
-    if (!ok) return 1;
+    if (!ok) return nonfinite ? 2 : 1;
     double l2 = 0;
     for (int i = tid; i < n; i += L::WGS) l2 += yrow[i] * yrow[i];
     l2 = block_sum<L::NWAVES>(l2, SD + L::RED);
@@ -587,7 +620,7 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
             double acc = cc < nb ? yrow[j0 + cc] : 0.0;
 #pragma unroll
             for (int m = cc + 1; m < NB; m++) if (m < nb) acc -= Hp[rbp[j0 + m] + j0 + cc] * z[m];
-            z[cc] = cc < nb ? acc / dg[j0 + cc] : 0.0;
+            z[cc] = cc < nb ? acc * dg[j0 + cc] : 0.0;
         }
         if (tid < NB && tid < nb) {
             double v = 0;
@@ -610,7 +643,7 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
     bool fin = isfinite(l2);
     for (int i = tid; i < n; i += L::WGS) {
         const int vi = i < M ? 6 + i : i - M;
-        const double dv = zl[i] * sc[i];
+        const double dv = zl[i];
         d[vi] = dv;
         if (!isfinite(dv)) fin = false;
     }

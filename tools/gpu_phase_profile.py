@@ -25,7 +25,7 @@ recs = batch.records()
 p = prof.cpu().numpy().reshape(-1, 16).astype(np.float64)
 names = ['phaseA', 'phaseB', 'reduce', 'factor', 'linesrch', 'total', 'ell_tot']
 n = recs['n_deform'] + 6
-cls = np.where(n <= 40, 'A', np.where(n <= 84, 'B', np.where(n <= 172, 'C', 'D')))
+cls = np.where(n <= 40, 'A', np.where(n <= 84, 'B', np.where(n <= 172, 'C', 'D')))  # size bands for reporting only
 print('cycles are shader-clock ticks of thread 0; ms = ticks / 2.4e6 (approx)')
 for c in 'ABCD':
     m = cls == c
