@@ -328,7 +328,10 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
     P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_meta = (uint32_t *)(b + p->off_ell_meta);
     P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc);
-    P.hess_thr = 0.05f;   // same constant as the oracle's ORC_HESS_THR
+#ifndef SDSM_HESS_THR
+#define SDSM_HESS_THR 0.1f    // same constant as the oracle's ORC_HESS_THR
+#endif
+    P.hess_thr = SDSM_HESS_THR;
     P.psf = (const float *)(b + p->off_psf);
     P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
     P.hglob = (double *)(b + p->off_hglob); P.hglob_stride = SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2;
