@@ -32,7 +32,9 @@ namespace {
 #define NEWTON_RELTOL 1e-6
 #define LS_ALPHA 0.01
 #define LS_BETA 0.5
-#define LS_MAX 40
+#define LS_K 8            // step lengths per line-search sweep
+#define LS_SWEEPS 5       // t0 * 2^-(8 s + k): down to 2^-39
+#define LS_T0_ELL 4.0     // elliptical solves start far from the optimum: longer first step
 #if defined(SDSM_PROFILE) && defined(SDSM_PROFILE_FINE)
 #define FINE_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #define FINE_ADD(slot) do { FINE_FENCE(); long long _t = PROF_NOW(); prof_acc[slot] += _t - ft; ft = _t; } while (0)
@@ -185,6 +187,83 @@ __device__ __noinline__ double eval_value(const Cand &c, int xo, int M)
         psi += o2 < 0 ? 0 : o2;
     }
     return psi;
+}
+
+// Line search sweep: psi(x + t_k d) for LS_K step lengths t_k = t0 * 2^-k in ONE pass over the pixels.  S is linear in
+// the parameters, S(x + t d) = S(x) + t S(d): the row of G~ is fetched once, applied to xi and to d_xi (interleaved pairs
+// (x_j, d_j) at L::XT .. so one 16-byte LDS read serves both), and only the loss is evaluated LS_K times.
+template <class L>
+__device__ __noinline__ void eval_line(const Cand &c, int M, double t0, double (&out)[LS_K])
+{
+    const int tid = threadIdx.x, n = 6 + M;
+    const double *x = SD + L::X, *d = SD + L::D;
+    double *xd = SD + L::XT;
+    __syncthreads();
+    for (int i = tid; i < n; i += L::WGS) { xd[2 * i] = x[i]; xd[2 * i + 1] = d[i]; }
+    __syncthreads();
+    double ps[LS_K];
+#pragma unroll
+    for (int k = 0; k < LS_K; k++) ps[k] = 0;
+    const bool in_regs = c.zmax <= ZREG;
+    for (int p = tid; p < c.N; p += L::WGS) {
+        const double yv = c.crop_y[p];
+        const uint32_t rc = c.crop_rc[p];
+        const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
+        const double q0 = u * u, q1 = v * v, q2 = 2 * (u * v), q3 = 2 * u, q4 = 2 * v;
+        double S0 = q0 * xd[0] + q1 * xd[2] + q2 * xd[4] + q3 * xd[6] + q4 * xd[8] + xd[10];
+        double Sd = q0 * xd[1] + q1 * xd[3] + q2 * xd[5] + q3 * xd[7] + q4 * xd[9] + xd[11];
+        if (M > 0) {
+            if (in_regs) {
+                float w[ZREG]; int id[ZREG];
+                load_row(c, p, w, id);
+                const int q0g = __builtin_amdgcn_readfirstlane(p) & ~63;
+#pragma unroll
+                for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
+                    if (q0g < c.gcount[j]) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const double wv = (double)w[4 * j + k];
+                            const double *pr = xd + 2 * (6 + id[4 * j + k]);
+                            S0 += wv * pr[0]; Sd += wv * pr[1];
+                        }
+                    }
+                }
+            } else {
+                const int nnz = (int)(c.ell_meta[p] & 0xffffu);
+                for (int s2 = 0; s2 < nnz; s2++) {
+                    const double wv = (double)ell_w_at(c, s2, p);
+                    const double *pr = xd + 2 * (6 + ell_i_at(c, s2, p));
+                    S0 += wv * pr[0]; Sd += wv * pr[1];
+                }
+            }
+        }
+        const double a0 = yv * S0, a1 = yv * Sd;
+        double tk = t0;
+#pragma unroll
+        for (int k = 0; k < LS_K; k++) {
+            const double t = a0 + tk * a1;
+            ps[k] += t >= -LOG_DBL_MAX ? log(1 + exp(-t)) : -t;
+            tk *= LS_BETA;
+        }
+    }
+    block_sum_vec<LS_K, L::NWAVES>(ps, SD + L::RED);
+    if (M > 0) {                                         // dsm.py:323-331
+        double rs[LS_K];
+#pragma unroll
+        for (int k = 0; k < LS_K; k++) rs[k] = 0;
+        for (int j = tid; j < M; j += L::WGS) {
+            const double xj = xd[2 * (6 + j)], dj = xd[2 * (6 + j) + 1];
+            double tk = t0;
+#pragma unroll
+            for (int k = 0; k < LS_K; k++) { const double xi = xj + tk * dj; rs[k] += sqrt(xi * xi + c.epsilon); tk *= LS_BETA; }
+        }
+        block_sum_vec<LS_K, L::NWAVES>(rs, SD + L::RED);
+#pragma unroll
+        for (int k = 0; k < LS_K; k++) { const double o2 = c.alpha * rs[k] - c.alpha * sqrt(c.epsilon) * M; ps[k] += o2 < 0 ? 0 : o2; }
+    }
+#pragma unroll
+    for (int k = 0; k < LS_K; k++) out[k] = ps[k];
+    __syncthreads();
 }
 
 // regulariser contributions to psi, gradient and Hessian diagonal (dsm.py:323-331, 349, 372-376)
@@ -661,7 +740,6 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
 {
     const int tid = threadIdx.x, n = 6 + M;
     double *x = SD + L::X, *xt = SD + L::XT, *d = SD + L::D;
-    double tprev = 1;
     int status = 1, iters = 0;
     for (;;) {
         double psi;
@@ -700,20 +778,26 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
             status = 0;
             break;
         }
-        double t = tprev * 2 < 1 ? tprev * 2 : 1;
+        // line search: sweeps of LS_K step lengths evaluated together; the accepted step is the one with the smallest f
+        // among those that satisfy the Armijo condition (same rule as the oracle)
         bool accepted = false;
-        for (int ls = 0; ls < LS_MAX; ls++) {
-            for (int i = tid; i < n; i += L::WGS) xt[i] = x[i] + t * d[i];
-            __syncthreads();
-            double ft = c.scale * eval_value<L>(c, L::XT, M);
+        double tbest = 0, fbest = INFINITY, t0 = M == 0 ? LS_T0_ELL : 1.0;
+        for (int sweep = 0; sweep < LS_SWEEPS && !accepted; sweep++) {
+            double fs[LS_K];
+            eval_line<L>(c, M, t0, fs);
             (*ev_value)++;
-            if (isfinite(ft) && ft <= f - LS_ALPHA * t * lam2) { accepted = true; break; }
-            t *= LS_BETA;
+            double tk = t0;
+#pragma unroll
+            for (int k = 0; k < LS_K; k++) {
+                const double ft = c.scale * fs[k];
+                if (isfinite(ft) && ft <= f - LS_ALPHA * tk * lam2 && ft < fbest) { fbest = ft; tbest = tk; accepted = true; }
+                tk *= LS_BETA;
+            }
+            t0 = tk;
         }
         PROF_ADD(4, pt);
         if (!accepted) { status = 1; break; }
-        tprev = t;
-        for (int i = tid; i < n; i += L::WGS) x[i] = xt[i];
+        for (int i = tid; i < n; i += L::WGS) x[i] += tbest * d[i];
         __syncthreads();
     }
     *psi_out = eval_value<L>(c, L::X, M);
