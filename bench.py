@@ -110,11 +110,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # latency of ONE step with nothing else in flight (wall clock per image)
+    # latency of ONE step with nothing else in flight (wall clock per image), scheduled for latency: the largest regions
+    # get a 512-thread workgroup each (sdsm_plan_set_latency_mode; same results, fewer solves per second under load)
+    lat = engine.Batch(img, fps, scene['dsm_cfg'], latency_mode=True)
+    lat.launch()
+    torch.cuda.synchronize()
     t1 = time.perf_counter()
-    batch.launch()
+    lat.launch()
     torch.cuda.synchronize()
     single_ms = (time.perf_counter() - t1) * 1e3
+    del lat
     L.sdsm_enable_kernel_timing(1)
     solve_ms = []
     # kernel-level timing with HIP events on the launch stream: a few extra, separately timed launches

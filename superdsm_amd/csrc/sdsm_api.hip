@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "sdsm_common.h"
+#include <climits>
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
                                         hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev, int n_c, int n_d);
@@ -117,6 +118,7 @@ struct sdsm_plan {
     std::vector<CandDesc> cand;
     std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those that may reach class C, then class D
     int n_order_c = 0, n_order_d = 0;
+    int wide_pixels = INT_MAX;   // throughput mode by default
     std::vector<float> psf;
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
@@ -201,7 +203,7 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     std::stable_sort(p->order.begin(), p->order.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
     // a candidate can only belong to a larger size class if its upper bound Mcap allows it: the larger classes get
     // their own (shorter) launch lists instead of n workgroups that exit immediately
-    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_K1_DENSE_N) { p->order.push_back(p->order[k]); p->n_order_c++; }
+    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_K1_DENSE_N || p->cand[p->order[k]].N > SDSM_WIDE_PIXELS) { p->order.push_back(p->order[k]); p->n_order_c++; }
     for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_ENV_DENSE_N) { p->order.push_back(p->order[k]); p->n_order_d++; }
     // workspace layout
     size_t o = 0;
@@ -230,6 +232,12 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
 }
 
 extern "C" void sdsm_plan_destroy(sdsm_plan *plan) { delete plan; }
+extern "C" int sdsm_plan_set_latency_mode(sdsm_plan *p, int on)
+{
+    if (!p) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_set_latency_mode: null plan");
+    p->wide_pixels = on ? SDSM_WIDE_PIXELS : INT_MAX;
+    return SDSM_OK;
+}
 extern "C" size_t sdsm_plan_workspace_bytes(const sdsm_plan *p) { return p ? p->total : 0; }
 extern "C" size_t sdsm_plan_mask_bytes(const sdsm_plan *p) { return p ? (size_t)std::max<int64_t>(p->total_mask_words, 1) * 4 : 0; }
 extern "C" int64_t sdsm_plan_total_pixels(const sdsm_plan *p) { return p ? p->total_pixels : 0; }
@@ -320,7 +328,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     BatchParams P{};
     P.n = p->n; P.H = p->H; P.W = p->W; P.n_atoms = p->n_atoms;
     P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.no_deform = p->no_deform;
-    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters;
+    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels;
     P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
     P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);
     P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);

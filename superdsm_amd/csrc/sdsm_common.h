@@ -26,6 +26,7 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
 #define SDSM_K1_NMAX 128           // solve class 1: 6 + M <= 128 and envelope <= SDSM_K1_EMAX doubles (LDS ~ 30 KB)
 #define SDSM_K1_EMAX 2560
+#define SDSM_WIDE_PIXELS 3072       // latency mode: larger regions go to class 2 (512 threads per candidate; a batch is as slow as its slowest candidate)
 #define SDSM_K2_EMAX 11000         // solve class 2: 6 + M <= SDSM_MAX_N_SOLVE and envelope <= 11000 doubles (LDS ~ 157 KB)
 #define SDSM_K1_DENSE_N 70         // 6 + M <= 70: even a dense triangle fits class 1
 #define SDSM_ENV_DENSE_N 146       // 6 + M <= 146: even a dense triangle fits class 2
@@ -78,7 +79,8 @@ struct BatchParams {
     int32_t n, H, W, n_atoms;
     int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, ELL slots per pixel (a multiple of 4)
     int32_t no_deform;                 // smooth_amount == inf
-    int32_t init_elliptical, max_iters, pad0;
+    int32_t init_elliptical, max_iters;
+    int32_t k1_pixmax;                 // regions with more pixels are solved by class 2 (INT_MAX: throughput mode)
     double scale, epsilon, alpha;
     float hess_thr; int32_t pad1;      // Hessian ignores row entries < hess_thr * row maximum (solver approximation)
     const CandDesc *cand;

@@ -22,6 +22,7 @@
 //   (A register-tiled dense J^T diag(d) J over LDS-staged Jacobian rows was measured 10 % slower even at 6+M <= 40
 //   once the Hessian was thresholded, and was removed.)
 #include "sdsm_common.h"
+#include <climits>
 
 extern __shared__ __align__(16) unsigned char sdsm_smem[];
 
@@ -486,8 +487,9 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 // 2 non-finite input.  *lam2 = -g.d.
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, double *lam2)
+__device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, double *lam2 PROF_PARAM)
 {
+    long long pf = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M;
     double *Hp = hess_ptr<L>(c), *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *zl = SD + L::XT;   // XT is free between line searches
@@ -585,6 +587,7 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
     }
     __syncthreads();
     bool ok = true, nonfinite = false;
+    PROF_ADD(13, pf);
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = n - j0 < NB ? n - j0 : NB;
         // A. diagonal block (rows j0 .. j0+3 all store column j0: fst is a multiple of 4)
@@ -686,6 +689,7 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
         }
     }
     __syncthreads();
+    PROF_ADD(14, pf);
     if (!ok) return nonfinite ? 2 : 1;
     double l2 = 0;
     for (int i = tid; i < n; i += L::WGS) l2 += yrow[i] * yrow[i];
@@ -728,6 +732,7 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
     }
     if (!fin) *flag = 1;
     __syncthreads();
+    PROF_ADD(15, pf);
     if (*flag) return 2;
     *lam2 = l2;
     return 0;
@@ -751,11 +756,11 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         if (iters >= max_iters) { status = 1; break; }
         if (!isfinite(f)) { status = 2; break; }
         double lam2u, tau = 0;
-        int fs = factor_solve<L>(c, M, tau, &lam2u);
+        int fs = factor_solve<L>(c, M, tau, &lam2u PROF_ARG);
         for (int attempt = 1; fs == 1 && attempt < 12; attempt++) {      // escalating diagonal shift (same schedule as the oracle)
             tau = tau == 0 ? 1e-12 : tau * 100;
             eval_full_sparse<L>(c, M PROF_ARG);                            // the failed factorisation overwrote the Hessian
-            fs = factor_solve<L>(c, M, tau, &lam2u);
+            fs = factor_solve<L>(c, M, tau, &lam2u PROF_ARG);
         }
         if (fs != 0) { status = 2; break; }
         double lam2 = c.scale * lam2u;
@@ -824,7 +829,7 @@ __device__ __forceinline__ void reparam(const double *th, double p0, double p1, 
 // limits of the previous class are passed at run time (nprev = 0 for the first class).  The first class also writes the
 // records of trivial / failed-setup candidates.
 template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256>
-__global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int nprev, int eprev, int handles_rest, sdsm_record *records,
+__global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records,
                                                               uint32_t *masks, double *xi_out)
 {
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
@@ -848,8 +853,8 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     if (6 + Mfull > SDSM_MAX_N_SOLVE) { unsupported = true; Mfull = 0; }     // elliptical result only (flagged)
     const int nfull = 6 + Mfull;
     const int efull = Mfull > 0 ? st.env_size : 21;
-    if (nfull <= nprev && efull <= eprev) return;                // an earlier class took it
-    if (!(nfull <= NMAX && efull <= EMAX)) return;               // a later class takes it
+    if (nfull <= nprev && efull <= eprev && cd.N <= pixprev) return;         // an earlier class took it
+    if (!(nfull <= NMAX && efull <= EMAX && cd.N <= pixmax)) return;         // a later class takes it
     if (GLOBALH && cd.hglob_slot < 0) {                          // cannot happen (the host reserves a slot whenever Mcap admits it)
         if (tid == 0) { sdsm_record r0 = {}; r0.status = SDSM_CAND_UNSUPPORTED; r0.n_pixels = cd.N; r0.n_deform = st.M; *rec = r0; }
         return;
@@ -1030,12 +1035,12 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 }
 
 // ---- launch helper (called from sdsm_api.hip) ----------------------------------------------------
-// class 1: 6 + M <= 128, envelope <= 2560 doubles   256 threads, LDS ~ 30 KB  (register bound: 2 workgroups / CU)
+// class 1: 6 + M <= 128, envelope <= 2560 doubles, <= P.k1_pixmax pixels   256 threads, LDS ~ 30 KB  (register bound: 2 workgroups / CU)
 // class 2: 6 + M <= 1024, envelope <= 11000 doubles 512 threads, LDS ~ 157 KB (1 workgroup / CU)
 // class 3: 6 + M <= 1024, any envelope              512 threads, Hessian in global memory (only launched when needed)
 // The classes are independent: they run concurrently on streams forked from the caller's stream.
 template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256>
-static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
+static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
     auto kern = sdsm_k_solve<NMAX, EMAX, WPE, GLOBALH, WGSIZE>;
     constexpr int lds = Lay<NMAX, EMAX, GLOBALH, WGSIZE>::TOTAL_BYTES;
@@ -1043,7 +1048,7 @@ static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int h
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     if (P.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nprev, eprev, handles_rest, records, masks, xi_out);
+    hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nprev, eprev, pixprev, pixmax, handles_rest, records, masks, xi_out);
     return hipGetLastError();
 }
 
@@ -1061,15 +1066,15 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     if (n_c > 0 || n_d > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
     if (n_d > 0) {
         if ((e = hipStreamWaitEvent(side3, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, INT_MAX, INT_MAX, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[3], side3)) != hipSuccess) return e;
     }
     if (n_c > 0) {
         if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512>(Pc, SDSM_K1_NMAX, SDSM_K1_EMAX, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512>(Pc, SDSM_K1_NMAX, SDSM_K1_EMAX, P.k1_pixmax, INT_MAX, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
     }
-    if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 2>(P, 0, 0, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
+    if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 2>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
     if (n_d > 0 && (e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
     if (n_c > 0 && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;

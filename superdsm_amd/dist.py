@@ -75,7 +75,7 @@ def _gpu_solve_local(image, footprints, cfg):
     """Default local solver of a shard: one engine batch on this rank's GPU.  Returns (records bytes, mask_info
     int32 [n,4], mask_offset int64 [n], masks bytes), all numpy."""
     from . import engine
-    batch = engine.Batch(image, footprints, cfg)
+    batch = engine.Batch(image, footprints, cfg, latency_mode=True)
     batch.launch()
     torch.cuda.synchronize(image.device)
     n = len(footprints)

@@ -73,7 +73,9 @@ class DeviceImage:
 class Batch:
     """One ``compute_objects`` call: plan, workspace, launch, results."""
 
-    def __init__(self, image, footprints, dsm_cfg, want_xi=False):
+    def __init__(self, image, footprints, dsm_cfg, want_xi=False, latency_mode=False):
+        """latency_mode: give the largest regions a 512-thread workgroup each (shortest wall clock of ONE batch);
+        default: most candidate solves per second with several batches in flight (sdsm_plan_set_latency_mode)."""
         L = _capi.lib()
         self.image = image
         self.n = len(footprints)
@@ -86,6 +88,8 @@ class Batch:
                                        self.n, offs.ctypes.data_as(C.c_void_p), labels.ctypes.data_as(C.c_void_p))
         if not self.plan:
             raise _capi.SdsmError('sdsm_plan_create failed: ' + L.sdsm_last_error().decode())
+        if latency_mode:
+            _capi.check(L.sdsm_plan_set_latency_mode(self.plan, 1), 'sdsm_plan_set_latency_mode')
         dev = image.device
         self.ws_bytes = L.sdsm_plan_workspace_bytes(self.plan)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)

@@ -128,7 +128,7 @@ def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAUL
     if shard is not None:
         records, fragments = shard.solve(image, footprints, cfg)
     else:
-        batch = engine.Batch(image, footprints, cfg)
+        batch = engine.Batch(image, footprints, cfg, latency_mode=True)     # one image at a time: shortest wall clock
         batch.launch()
         torch.cuda.synchronize(image.device)
         records = batch.records()

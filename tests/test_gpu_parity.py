@@ -426,3 +426,24 @@ def test_sharder_single_rank_equals_direct_batch(gpu):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_latency_mode_gives_the_same_results(gpu):
+    """sdsm_plan_set_latency_mode only changes which workgroup size solves the large regions."""
+    from superdsm_amd import engine, testing
+    scene = testing.make_scene('bbbc039_like', max_size=2)
+    fps = scene['footprints'][-40:]                     # the cluster universes: the largest regions of the image
+    img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
+    cfg = {k: v for k, v in scene['dsm_cfg'].items() if k != 'background_margin'}
+    out = []
+    for mode in (False, True):
+        b = engine.Batch(img, fps, cfg, latency_mode=mode)
+        b.launch()
+        gpu.cuda.synchronize()
+        out.append((b.records(), b.fragments(b.records())))
+    (r0, f0), (r1, f1) = out
+    assert (r0['n_pixels'] > 3072).any(), 'the sample must contain regions that change class'
+    assert (r0['status'] == r1['status']).all() and (r0['n_deform'] == r1['n_deform']).all()
+    np.testing.assert_allclose(r1['energy'], r0['energy'], rtol=1e-6, atol=1e-9)
+    for a, b in zip(f0, f1):
+        assert testing.dice(a[0], a[1], b[0], b[1], scene['y'].shape) >= 0.999

@@ -41,6 +41,9 @@ for c in 'ABCD':
 worst = np.argsort(-p[:, 5])[:8]
 if p[:, 8:13].sum() > 0:
     print('fine sections of the sparse pixel pass (thread 0, fenced): loads %.1f%%  gather %.1f%%  loss+sums %.1f%%  grad atomics %.1f%%  hess atomics %.1f%%' % tuple(100 * p[:, 8:13].sum(0) / p[:, 8:13].sum()))
+if p[:, 13:16].sum() > 0:
+    m = cls == 'B'
+    print('factor_solve parts, class B, us per call (median): head %.1f  panels %.1f  l2 + back substitution %.1f' % tuple(np.median(p[m, 13 + i] / np.maximum(recs['iters_dsm'][m], 1)) / 2400 for i in range(3)))
 print('slowest candidates:')
 for k in worst:
     print('  cand %d N=%d M=%d it_ell=%d it_dsm=%d evals=%d/%d total=%.2f ms  A=%.2f B=%.2f red=%.2f fac=%.2f ls=%.2f' % (
