@@ -138,10 +138,11 @@ int sdsm_batch_launch(const sdsm_plan *plan, const double *d_y, const int32_t *d
                       double *d_xi, void *stream);
 int64_t sdsm_plan_xi_count(const sdsm_plan *plan);
 /* Workspace layout for inspection (parity tests of the crops / grid / G~ rows).  out[16], byte offsets into the
- * workspace: 0 cand table, 1 cand state (M, status, ...: 64 B each), 2 crop_y f64, 3 crop_rc u32, 4 crop_cc u32,
- * 5 ell_nnz u16, 6 grid u32, 7 ell_idx u16, 8 ell_w f32; then 9 zcap, 10 k, 11 sizeof(cand entry),
- * 12 total_pixels, 13 total_ell entries; 14-15 reserved.  Candidate i's blocks start at crop offset
- * sum(n_pixels[:i]), ELL offset that * zcap (slot-major inside the candidate) and grid offset xi_offset[i]. */
+ * workspace: 0 cand table, 1 cand state (M, status, ...), 2 crop_y f64, 3 crop_rc u32, 4 crop_cc u32 (setup order),
+ * 5 ell_meta u32 (row entries | Hessian entries << 16), 6 grid u32, 7 ell_idx u16, 8 ell_w f32; then 9 zcap (entries
+ * per row, a multiple of 4), 10 k, 11 sizeof(cand entry), 12 total_pixels, 13 total_ell entries, 14 sizeof(cand state);
+ * 15 reserved.  Candidate i's blocks start at crop offset sum(n_pixels[:i]), G~ offset that * zcap -- entry s of crop
+ * position p at element ((s / 4) * N + p) * 4 + s % 4 of the candidate's block -- and grid offset xi_offset[i]. */
 int sdsm_plan_layout(const sdsm_plan *plan, int64_t *out);
 /* Scheduling of one batch.  Throughput mode (default): every candidate whose system fits is solved by a 256-thread
  * workgroup, two per compute unit -- most candidate solves per second when several batches are in flight.  Latency mode

@@ -44,5 +44,25 @@ out = dict(
     solve_fetch_bytes_per_launch_raw=solve_fetch, solve_fetch_bytes_per_launch_x2=2 * solve_fetch,
     solve_write_bytes_per_launch=solve_write,
     solve_hbm_bytes_per_launch=solve_fetch + solve_write)
+sq = {}
+files = glob.glob(os.path.join(root, 'gpurun_out', f'{tag}_sq', '*', '*counter_collection.csv'))
+if files:
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(files[0])):
+        if 'sdsm_k_solve<128' in r['Kernel_Name']:
+            agg['solve class 1'][r['Counter_Name']].append(float(r['Counter_Value']))
+        elif 'sdsm_k_setup' in r['Kernel_Name']:
+            agg['setup'][r['Counter_Name']].append(float(r['Counter_Value']))
+    sq = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+    for k, d in sq.items():
+        wc = d.get('SQ_WAVE_CYCLES', 0)
+        if wc:
+            d['frac_wave_parked_on_waitcnt_or_barrier'] = d.get('SQ_WAIT_ANY', 0) / wc
+            d['frac_issue_stalled'] = d.get('SQ_WAIT_INST_ANY', 0) / wc
+            d['frac_issuing'] = d.get('SQ_ACTIVE_INST_ANY', 0) / wc
+        if d.get('SQ_LDS_IDX_ACTIVE'):
+            d['lds_bank_conflict_share_of_lds_cycles'] = d.get('SQ_LDS_BANK_CONFLICT', 0) / d['SQ_LDS_IDX_ACTIVE']
+out['sq_counters_per_launch'] = sq
+out['sq_note'] = 'separate pass: --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; averages per launch'
 json.dump(out, open(os.path.join(root, 'profiles', f'{tag}_pmc_summary.json'), 'w'), indent=1)
 print(json.dumps({k: out[k] for k in out if k.startswith('solve_')}, indent=1))
