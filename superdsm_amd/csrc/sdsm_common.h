@@ -135,25 +135,62 @@ __device__ __forceinline__ double block_sum(double v, double *scratch)
     return r;
 }
 
-// Sums K values over the workgroup with ONE barrier pair; results broadcast.  scratch: SDSM_WAVES * K doubles.
+// Sums K values over the workgroup.  Within a wavefront a reduce-scatter butterfly: at each of the first log2(KP) steps a
+// lane keeps one half of its values and sends the other half to its partner (KP/2 + KP/4 + ... + 1 shuffles instead of
+// K per step), so after the 6 steps lane l holds the wavefront total of value l >> (6 - log2 KP).  One LDS hop across the
+// wavefronts; totals are then read back with sum_scatter_total (any thread, any index).  scratch: WAVES * KP doubles.
+template <int K> struct SdsmPow2 { static constexpr int v = K <= 1 ? 1 : 2 * SdsmPow2<(K + 1) / 2>::v; };
+template <int KP> struct SdsmLog2 { static constexpr int v = KP <= 1 ? 0 : 1 + SdsmLog2<KP / 2>::v; };
+
+template <int K, int WAVES = SDSM_WAVES>
+__device__ __forceinline__ void block_sum_scatter(const double (&v)[K], double *scratch)
+{
+    constexpr int KP = SdsmPow2<K>::v;
+    static_assert(KP <= 64, "at most 64 values");
+    constexpr int SH = 6 - SdsmLog2<KP>::v;
+    double t[KP];
+#pragma unroll
+    for (int i = 0; i < KP; i++) t[i] = i < K ? v[i] : 0.0;
+    const int lane = threadIdx.x & 63;
+    int c = KP;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        if (c > 1) {
+            const bool bit = (lane & o) != 0;
+            const int h = c / 2;
+#pragma unroll
+            for (int i = 0; i < KP / 2; i++) {
+                if (i < h) {
+                    const double lo = t[i], hi = t[i + h];
+                    const double send = bit ? lo : hi, keep = bit ? hi : lo;
+                    t[i] = keep + __shfl_xor(send, o);
+                }
+            }
+            c = h;
+        } else t[0] += __shfl_xor(t[0], o);
+    }
+    __syncthreads();                                   // scratch may still be read by the previous user
+    if ((lane & ((1 << SH) - 1)) == 0) scratch[(threadIdx.x >> 6) * KP + (lane >> SH)] = t[0];
+    __syncthreads();
+}
+
+template <int K, int WAVES = SDSM_WAVES>
+__device__ __forceinline__ double sum_scatter_total(const double *scratch, int k)
+{
+    constexpr int KP = SdsmPow2<K>::v;
+    double r = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) r += scratch[w * KP + k];
+    return r;
+}
+
+// Same, every thread gets every total.
 template <int K, int WAVES = SDSM_WAVES>
 __device__ __forceinline__ void block_sum_vec(double (&v)[K], double *scratch)
 {
+    block_sum_scatter<K, WAVES>(v, scratch);
 #pragma unroll
-    for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < K; k++) scratch[(threadIdx.x >> 6) * K + k] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        double r = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; w++) r += scratch[w * K + k];
-        v[k] = r;
-    }
+    for (int k = 0; k < K; k++) v[k] = sum_scatter_total<K, WAVES>(scratch, k);
 }
 
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, unsigned long long *scratch)

@@ -317,22 +317,13 @@ __device__ __noinline__ double eval_full_ell(const Cand &c PROF_PARAM)
             for (int b = 0; b <= a; b++) red[7 + a * (a + 1) / 2 + b] += dc * q[a] * q[b];   // static index: stays in registers
     }
     PROF_ADD(0, pt);
-    block_sum_vec<28, L::NWAVES>(red, SD + L::RED);
-    if (tid < 6) {
-        double gv = 0;
-#pragma unroll
-        for (int e = 0; e < 6; e++) gv = tid == e ? red[1 + e] : gv;
-        g[tid] = gv;
-    }
-    if (tid < 21) {
-        double hv = 0;
-#pragma unroll
-        for (int e = 0; e < 21; e++) hv = tid == e ? red[7 + e] : hv;     // select instead of a dynamic register index
-        Hp[tid] = hv;
-    }          // packed lower triangle of a 6x6 matrix = the same enumeration order
+    block_sum_scatter<28, L::NWAVES>(red, SD + L::RED);
+    if (tid < 6) g[tid] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 1 + tid);
+    if (tid < 21) Hp[tid] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 7 + tid);   // packed lower triangle of a 6x6 matrix = the same enumeration order
+    const double psi = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 0);
     __syncthreads();
     PROF_ADD(2, pt);
-    return red[0];
+    return psi;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -443,23 +434,15 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
         FINE_ADD(12);
     }
     PROF_ADD(0, pt);
-    block_sum_vec<28, L::NWAVES>(red, SD + L::RED);
-    if (tid < 6) {
-        double gv = 0;
-#pragma unroll
-        for (int e = 0; e < 6; e++) gv = tid == e ? red[1 + e] : gv;
-        g[tid] = gv;
-    }
+    block_sum_scatter<28, L::NWAVES>(red, SD + L::RED);
+    if (tid < 6) g[tid] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 1 + tid);
     if (tid < 21) {
-        double hv = 0;
-#pragma unroll
-        for (int e = 0; e < 21; e++) hv = tid == e ? red[7 + e] : hv;
         int a = 0;
         while ((a + 1) * (a + 2) / 2 <= tid) a++;
-        Hp[rbp[M + a] + M + (tid - a * (a + 1) / 2)] = hv;      // theta-theta block: columns M .. M + a of row M + a
+        Hp[rbp[M + a] + M + (tid - a * (a + 1) / 2)] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 7 + tid);   // theta-theta block: columns M .. M + a of row M + a
     }
+    double psi = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 0);
     __syncthreads();
-    double psi = red[0];
     if (M > 0) psi += add_regulariser<L>(c, M);
     __syncthreads();
     PROF_ADD(2, pt);
