@@ -388,10 +388,22 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
                 lo++; hi--;
             }
             hz = lo;
+            // the Hessian entries in ascending column order (the solve kernel then knows which of a pair is the row)
+            for (int a = 1; a < hz; a++) {
+                const int64_t ea = ell_at(c.base, cd.N, a);
+                const uint16_t ia = P.ell_idx[ea]; const float wa = P.ell_w[ea];
+                int b = a - 1;
+                while (b >= 0 && P.ell_idx[ell_at(c.base, cd.N, b)] > ia) {
+                    const int64_t eb = ell_at(c.base, cd.N, b), eb1 = ell_at(c.base, cd.N, b + 1);
+                    P.ell_idx[eb1] = P.ell_idx[eb]; P.ell_w[eb1] = P.ell_w[eb];
+                    b--;
+                }
+                const int64_t eb1 = ell_at(c.base, cd.N, b + 1);
+                P.ell_idx[eb1] = ia; P.ell_w[eb1] = wa;
+            }
             // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
-            int mn = 1 << 30;
-            for (int a = 0; a < hz; a++) { const int ia = P.ell_idx[ell_at(c.base, cd.N, a)]; mn = ia < mn ? ia : mn; }
-            for (int a = 0; a < hz; a++) atomicMin(&efirst[P.ell_idx[ell_at(c.base, cd.N, a)]], mn);
+            const int mn = P.ell_idx[ell_at(c.base, cd.N, 0)];
+            for (int a = 1; a < hz; a++) atomicMin(&efirst[P.ell_idx[ell_at(c.base, cd.N, a)]], mn);
         }
         P.ell_meta[cd.crop_off + pos] = (uint32_t)c.nnz | ((uint32_t)hz << 16);
         zmax = c.nnz > zmax ? c.nnz : zmax;

@@ -45,6 +45,9 @@ namespace {
 #define FINE_START() do { } while (0)
 #endif
 #define ZREG (4 * SDSM_ELL_GROUPS_REG)   // ELL slots held in registers by the sparse path (covers zcap = 25 of the default ratios)
+#ifndef SDSM_FACTOR_DIV
+#define SDSM_FACTOR_DIV 1
+#endif
 #define HZREG 12         // leading ('significant') slots unrolled for the approximate Hessian
 
 // Compile-time LDS layout (offsets in doubles from the start of dynamic LDS).
@@ -472,10 +475,7 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
 #pragma unroll
                             for (int b = 0; b < 6; b++) atomicAdd(&Hp[rbt[b] + ia], dwa * q[b]);      // theta rows, column xi_ia
 #pragma unroll
-                            for (int b = 0; b <= a; b++) {
-                                const int ib = id[b];
-                                atomicAdd(&Hp[ia >= ib ? rbs[a] + ib : rbs[b] + ia], dwa * (double)w[b]);
-                            }
+                            for (int b = 0; b <= a; b++) atomicAdd(&Hp[rbs[a] + id[b]], dwa * (double)w[b]);   // leading entries are in ascending column order
                         }
                     }
                 } else {
@@ -570,7 +570,7 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
 
     if (M == 0) {
         // ---- elliptical model: 6 x 6 system solved redundantly by every thread in registers (no barriers) ----
-        double A[6][6], bb[6], s6[6], z[6];
+        double A[6][6], bb[6], s6[6], z[6], ri6[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) s6[i] = sc[i];
         double tau = tau_in;
@@ -589,19 +589,20 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
 #pragma unroll
                 for (int k = 0; k < j; k++) piv -= A[j][k] * A[j][k];
                 if (!(piv > 1e-300) || !isfinite(piv)) { ok = false; piv = 1; }
-                const double ljj = sqrt(piv);
-                A[j][j] = ljj;
+                const double rj = rsqrt_f64(piv);                 // reciprocal pivot: multiplications instead of divisions
+                ri6[j] = rj;
+                A[j][j] = piv * rj;
 #pragma unroll
                 for (int i = j + 1; i < 6; i++) {
                     double v = A[i][j];
 #pragma unroll
                     for (int k = 0; k < j; k++) v -= A[i][k] * A[j][k];
-                    A[i][j] = v / ljj;
+                    A[i][j] = v * rj;
                 }
                 double v = bb[j];
 #pragma unroll
                 for (int k = 0; k < j; k++) v -= z[k] * A[j][k];
-                z[j] = v / ljj;                                   // forward substitution rides along
+                z[j] = v * rj;                                    // forward substitution rides along
             }
             if (!ok) tau = tau == 0 ? 1e-12 : tau * 100;
         }
@@ -614,7 +615,7 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
             double v = z[k];
 #pragma unroll
             for (int m = k + 1; m < 6; m++) v -= A[m][k] * z[m];
-            z[k] = v / A[k][k];
+            z[k] = v * ri6[k];
         }
         bool fin = isfinite(l2);
 #pragma unroll
@@ -632,21 +633,34 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
     //      (reciprocal square roots, no divisions), reads the RAW panel entries of the rows / columns it updates, solves
     //      them against the block in registers and applies the rank-4 update; the factored block and the solved panel
     //      entries are written after the barrier (nobody reads those columns again before the back substitution).
+    //      WGS / SDSM_FACTOR_DIV threads take part (measured: 1 = all threads is fastest, 172 k vs 168 k (2) vs 156 k (4)
+    //      candidate solves/s: the panel chain is latency bound, more threads = fewer serial entries per thread).
     constexpr int NB = 4;
-    constexpr int GR = L::WGS / 16;                             // thread grid GR x 16 over the active rows x columns
+    constexpr int FT = L::WGS / SDSM_FACTOR_DIV;                // threads that factor
+    constexpr int GR = FT / 16;                                 // thread grid GR x 16 over the active rows x columns
     const int ri = tid >> 4, ki = tid & 15;
+    const bool fa = tid < FT;
+    int *pflag = (int *)(SD + L::FLAG);                         // [2]: panel p reports a failed pivot in slot p & 1
     for (int i = tid; i < n; i += L::WGS) {
         const int vi = i < M ? 6 + i : i - M;
         yrow[i] = -g[vi];
         if (tau_in > 0) Hp[rbp[i] + i] *= 1 + tau_in;
     }
+    if (tid < 2) pflag[tid] = 0;
     __syncthreads();
     bool ok = true, nonfinite = false;
+    int failed = 0;
     PROF_ADD(13, pf);
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = n - j0 < NB ? n - j0 : NB;
-        // A. diagonal block (rows j0 .. j0+3 all store column j0: fst is a multiple of 4)
+        const int jn = j0 + nb;
+        const int re = j0 < M ? rendp[j0 >> 2] : M - 1;
+        const int nxi = jn < M && re >= jn ? re - jn + 1 : 0;
+        const int th0 = jn > M ? jn : M;
+        const int na = nxi + (n - th0) + 1;
         double t[NB][NB], rinv[NB];
+        if (fa) {
+        // A. diagonal block (rows j0 .. j0+3 all store column j0: fst is a multiple of 4)
 #pragma unroll
         for (int a2 = 0; a2 < NB; a2++)
 #pragma unroll
@@ -668,13 +682,8 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
                 t[a2][cc] = v * r;
             }
         }
-        if (!ok) break;                                        // uniform: every thread computed the same block
+        if (!ok && tid == 0) pflag[(j0 >> 2) & 1] = nonfinite ? 2 : 1;
         // active rows below the panel: xi rows jn .. re, theta rows, right-hand side (compact index -> logical row)
-        const int jn = j0 + nb;
-        const int re = j0 < M ? rendp[j0 >> 2] : M - 1;
-        const int nxi = jn < M && re >= jn ? re - jn + 1 : 0;
-        const int th0 = jn > M ? jn : M;
-        const int na = nxi + (n - th0) + 1;
         // B. rank-nb update of the active rows x active columns from the raw panel entries
         for (int ti = ri; ti < na; ti += GR) {
             const int i = ti < nxi ? jn + ti : th0 + (ti - nxi);          // == n for the right-hand side
@@ -709,7 +718,10 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
                 Li[k] = acc;
             }
         }
+        }
         __syncthreads();
+        failed = pflag[(j0 >> 2) & 1];                         // uniform (two slots: a thread is at most one panel ahead)
+        if (failed) break;
         // C. factored block, reciprocal diagonal and solved panel entries (columns j0 .. j0+3: not read again before
         //    the back substitution, so the next panel starts without another barrier)
         if (tid < NB * NB) {
@@ -726,7 +738,7 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
                 if (a2 == b2) dg[j0 + a2] = rv;
             }
         }
-        for (int tt = tid; tt < na; tt += L::WGS) {
+        if (fa) for (int tt = tid; tt < na; tt += FT) {
             const int i = tt < nxi ? jn + tt : th0 + (tt - nxi);
             double *row = i < n ? Hp + rbp[i] + j0 : yrow + j0;
             double v[NB];
@@ -745,36 +757,39 @@ __device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, do
     }
     __syncthreads();
     PROF_ADD(14, pf);
-    if (!ok) return nonfinite ? 2 : 1;
+    if (failed) return failed;
     double l2 = 0;
     for (int i = tid; i < n; i += L::WGS) l2 += yrow[i] * yrow[i];
     l2 = block_sum<L::NWAVES>(l2, SD + L::RED);
-    // back substitution L^T z = yrow, blocked the same way: every thread solves the NB x NB block redundantly
+    // back substitution L^T z = yrow, blocked the same way: the threads that have a row to update (or write the block's
+    // solution) solve the NB x NB block redundantly
     for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
         const int nb = n - j0 < NB ? n - j0 : NB;
-        double z[NB];
-#pragma unroll
-        for (int cc = NB - 1; cc >= 0; cc--) {
-            double acc = cc < nb ? yrow[j0 + cc] : 0.0;
-#pragma unroll
-            for (int m = cc + 1; m < NB; m++) if (m < nb) acc -= Hp[rbp[j0 + m] + j0 + cc] * z[m];
-            z[cc] = cc < nb ? acc * dg[j0 + cc] : 0.0;
-        }
-        if (tid < NB && tid < nb) {
-            double v = 0;
-#pragma unroll
-            for (int x2 = 0; x2 < NB; x2++) v = x2 == tid ? z[x2] : v;
-            zl[j0 + tid] = v;
-        }
         int f4[NB];
 #pragma unroll
         for (int cc = 0; cc < NB; cc++) f4[cc] = cc < nb ? fstp[j0 + cc] : j0;
         const int start = j0 + nb - 1 >= M ? 0 : f4[0];          // fst is non-decreasing over the xi rows, 0 for theta rows
-        for (int i = start + tid; i < j0; i += L::WGS) {
-            double acc = yrow[i];
+        if (tid < NB || start + tid < j0) {
+            double z[NB];
 #pragma unroll
-            for (int cc = 0; cc < NB; cc++) if (cc < nb && i >= f4[cc]) acc -= Hp[rbp[j0 + cc] + i] * z[cc];
-            yrow[i] = acc;
+            for (int cc = NB - 1; cc >= 0; cc--) {
+                double acc = cc < nb ? yrow[j0 + cc] : 0.0;
+#pragma unroll
+                for (int m = cc + 1; m < NB; m++) if (m < nb) acc -= Hp[rbp[j0 + m] + j0 + cc] * z[m];
+                z[cc] = cc < nb ? acc * dg[j0 + cc] : 0.0;
+            }
+            if (tid < NB && tid < nb) {
+                double v = 0;
+#pragma unroll
+                for (int x2 = 0; x2 < NB; x2++) v = x2 == tid ? z[x2] : v;
+                zl[j0 + tid] = v;
+            }
+            for (int i = start + tid; i < j0; i += L::WGS) {
+                double acc = yrow[i];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) if (cc < nb && i >= f4[cc]) acc -= Hp[rbp[j0 + cc] + i] * z[cc];
+                yrow[i] = acc;
+            }
         }
         __syncthreads();
     }
