@@ -93,6 +93,31 @@ struct Cand {                       // per-candidate global pointers (already of
     double scale, epsilon, alpha;
 };
 
+// The evaluators are real (non-inlined) functions and receive the candidate by reference: its fields then come out of a
+// stack object through vector loads and look lane-varying to the compiler (64-bit address arithmetic in VALU, every field
+// in VGPRs).  They are the same for all lanes: readfirstlane moves them to SGPRs (scalar address arithmetic, SGPR-base
+// global loads, ~40 VGPRs less).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double uni(double v) { return __longlong_as_double((long long)uni((unsigned long long)__double_as_longlong(v))); }
+template <class T> __device__ __forceinline__ T SDSM_GLOBAL *uni(T SDSM_GLOBAL *p) { return (T SDSM_GLOBAL *)uni((unsigned long long)p); }
+__device__ __forceinline__ Cand uniform_cand(const Cand &c)
+{
+    Cand u;
+    u.crop_y = uni(c.crop_y); u.crop_rc = uni(c.crop_rc); u.ell_w4 = uni(c.ell_w4); u.ell_i4 = uni(c.ell_i4); u.ell_meta = uni(c.ell_meta);
+#pragma unroll
+    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) u.gcount[j] = uni(c.gcount[j]);
+    u.hglob = (double *)uni((unsigned long long)c.hglob);
+    u.N = uni(c.N); u.zmax = uni(c.zmax); u.hzmax = uni(c.hzmax); u.env_size = uni(c.env_size);
+    u.rmid = uni(c.rmid); u.cmid = uni(c.cmid); u.inv_hr = uni(c.inv_hr); u.inv_hc = uni(c.inv_hc);
+    u.scale = uni(c.scale); u.epsilon = uni(c.epsilon); u.alpha = uni(c.alpha);
+    return u;
+}
+
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
 
 template <class L> __device__ __forceinline__ double *hess_ptr(const Cand &c) { if constexpr (L::GLOBAL_H) return c.hglob; else return SD + L::HP; }
@@ -242,8 +267,9 @@ __device__ __forceinline__ double smooth_term(const Cand &c, const double *xv, i
 
 // psi only (line search, final energy).  Result broadcast to all threads.
 template <class L>
-__device__ __noinline__ double eval_value(const Cand &c, int xo, int M)
+__device__ __noinline__ double eval_value(const Cand &c_in, int xo, int M)
 {
+    const Cand c = uniform_cand(c_in);
     const double *xv = SD + xo;
     double psi = 0;
     for (int p = threadIdx.x; p < c.N; p += L::WGS) {
@@ -269,8 +295,9 @@ __device__ __noinline__ double eval_value(const Cand &c, int xo, int M)
 // the parameters, S(x + t d) = S(x) + t S(d): the row of G~ is fetched once, applied to xi and to d_xi (interleaved pairs
 // (x_j, d_j) at L::XT .. so one 16-byte LDS read serves both), and only the loss is evaluated LS_K times.
 template <class L>
-__device__ __noinline__ void eval_line(const Cand &c, int M, double t0, double (&out)[LS_K])
+__device__ __noinline__ void eval_line(const Cand &c_in, int M, double t0, double (&out)[LS_K])
 {
+    const Cand c = uniform_cand(c_in);
     const int tid = threadIdx.x, n = 6 + M;
     const double *x = SD + L::X, *d = SD + L::D;
     double *xd = SD + L::XT;
@@ -366,8 +393,9 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M)
 // per-lane register sums over the lane's pixels, reduced with wavefront shuffles + one LDS hop.
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ double eval_full_ell(const Cand &c PROF_PARAM)
+__device__ __noinline__ double eval_full_ell(const Cand &c_in PROF_PARAM)
 {
+    const Cand c = uniform_cand(c_in);
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
     double *Hp = hess_ptr<L>(c), *g = SD + L::G;
@@ -405,8 +433,9 @@ __device__ __noinline__ double eval_full_ell(const Cand &c PROF_PARAM)
 // SPARSE full evaluation (n > 40): per-pixel products added into the packed Hessian in LDS (ds_add_f64).
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ double eval_full_sparse(const Cand &c, int M PROF_PARAM)
+__device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M PROF_PARAM)
 {
+    const Cand c = uniform_cand(c_in);
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M;
@@ -542,8 +571,9 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 // 2 non-finite input.  *lam2 = -g.d.
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ int factor_solve(const Cand &c, int M, double tau_in, double *lam2 PROF_PARAM)
+__device__ __noinline__ int factor_solve(const Cand &c_in, int M, double tau_in, double *lam2 PROF_PARAM)
 {
+    const Cand c = uniform_cand(c_in);
     long long pf = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M;
