@@ -267,9 +267,11 @@ __device__ __forceinline__ double smooth_term(const Cand &c, const double *xv, i
 
 // psi only (line search, final energy).  Result broadcast to all threads.
 template <class L>
-__device__ __noinline__ double eval_value(const Cand &c_in, int xo, int M)
+__device__ __noinline__ double eval_value(const Cand &c_in, int xo_in, int M_in)
 {
     const Cand c = uniform_cand(c_in);
+    const int xo = uni(xo_in);
+    const int M = uni(M_in);
     const double *xv = SD + xo;
     double psi = 0;
     for (int p = threadIdx.x; p < c.N; p += L::WGS) {
@@ -295,9 +297,11 @@ __device__ __noinline__ double eval_value(const Cand &c_in, int xo, int M)
 // the parameters, S(x + t d) = S(x) + t S(d): the row of G~ is fetched once, applied to xi and to d_xi (interleaved pairs
 // (x_j, d_j) at L::XT .. so one 16-byte LDS read serves both), and only the loss is evaluated LS_K times.
 template <class L>
-__device__ __noinline__ void eval_line(const Cand &c_in, int M, double t0, double (&out)[LS_K])
+__device__ __noinline__ void eval_line(const Cand &c_in, int M_in, double t0_in, double (&out)[LS_K])
 {
     const Cand c = uniform_cand(c_in);
+    const int M = uni(M_in);
+    const double t0 = uni(t0_in);
     const int tid = threadIdx.x, n = 6 + M;
     const double *x = SD + L::X, *d = SD + L::D;
     double *xd = SD + L::XT;
@@ -433,9 +437,10 @@ __device__ __noinline__ double eval_full_ell(const Cand &c_in PROF_PARAM)
 // SPARSE full evaluation (n > 40): per-pixel products added into the packed Hessian in LDS (ds_add_f64).
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M PROF_PARAM)
+__device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M_in PROF_PARAM)
 {
     const Cand c = uniform_cand(c_in);
+    const int M = uni(M_in);
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M;
@@ -571,9 +576,11 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 // 2 non-finite input.  *lam2 = -g.d.
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ int factor_solve(const Cand &c_in, int M, double tau_in, double *lam2 PROF_PARAM)
+__device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_in_in, double *lam2 PROF_PARAM)
 {
     const Cand c = uniform_cand(c_in);
+    const int M = uni(M_in);
+    const double tau_in = uni(tau_in_in);
     long long pf = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M;
@@ -684,7 +691,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M, double tau_in,
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = n - j0 < NB ? n - j0 : NB;
         const int jn = j0 + nb;
-        const int re = j0 < M ? rendp[j0 >> 2] : M - 1;
+        const int re = j0 < M ? uni(rendp[j0 >> 2]) : M - 1;      // uniform: keep the panel's index arithmetic scalar
         const int nxi = jn < M && re >= jn ? re - jn + 1 : 0;
         const int th0 = jn > M ? jn : M;
         const int na = nxi + (n - th0) + 1;
@@ -692,9 +699,11 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M, double tau_in,
         if (fa) {
         // A. diagonal block (rows j0 .. j0+3 all store column j0: fst is a multiple of 4)
 #pragma unroll
-        for (int a2 = 0; a2 < NB; a2++)
+        for (int a2 = 0; a2 < NB; a2++) {
+            const int rba = a2 < nb ? uni(rbp[j0 + a2]) : 0;
 #pragma unroll
-            for (int b2 = 0; b2 <= a2; b2++) t[a2][b2] = a2 < nb ? Hp[rbp[j0 + a2] + j0 + b2] : (a2 == b2 ? 1.0 : 0.0);
+            for (int b2 = 0; b2 <= a2; b2++) t[a2][b2] = a2 < nb ? Hp[rba + j0 + b2] : (a2 == b2 ? 1.0 : 0.0);
+        }
 #pragma unroll
         for (int cc = 0; cc < NB; cc++) {
             double piv = t[cc][cc];
@@ -797,7 +806,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M, double tau_in,
         const int nb = n - j0 < NB ? n - j0 : NB;
         int f4[NB];
 #pragma unroll
-        for (int cc = 0; cc < NB; cc++) f4[cc] = cc < nb ? fstp[j0 + cc] : j0;
+        for (int cc = 0; cc < NB; cc++) f4[cc] = cc < nb ? uni(fstp[j0 + cc]) : j0;
         const int start = j0 + nb - 1 >= M ? 0 : f4[0];          // fst is non-decreasing over the xi rows, 0 for theta rows
         if (tid < NB || start + tid < j0) {
             double z[NB];
