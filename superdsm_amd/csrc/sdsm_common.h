@@ -32,6 +32,9 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_ENV_DENSE_N 146       // 6 + M <= 146: even a dense triangle fits class 2
 #define SDSM_ELL_GROUPS_REG 7       // groups of 4 G~ row entries the solve kernel keeps in registers (rows of <= 28 entries)
 #define SDSM_MAX_ELL_GROUPS 256    // zcap <= 1024 entries per row of G~ (a solvable candidate has M <= 1018 columns)
+#ifndef SDSM_PANEL
+#define SDSM_PANEL 4               // columns per panel (8 measured slower: 195 k vs 200 k solves/s); of the envelope Cholesky; first stored columns are multiples of it
+#endif
 #define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the largest solve class (Hessian + factor in global memory)
 
 #ifdef SDSM_PROFILE
@@ -102,7 +105,7 @@ struct BatchParams {
     uint32_t *ell_meta;                // entries of the row | entries used by the solver's approximate Hessian << 16
     // Envelope of the solver's Hessian, unknowns ordered xi_0 .. xi_{M-1}, theta_0 .. theta_5: row a of the xi block
     // stores columns env_fst[a] .. a (env_fst: smallest column any pixel couples a with, made non-decreasing in a and a
-    // multiple of 4), entry (a, b) at env_rb[a] + b; the 6 theta rows are dense and follow.  Indexed by xi_off + a.
+    // multiple of SDSM_PANEL), entry (a, b) at env_rb[a] + b; the 6 theta rows are dense and follow.  Indexed by xi_off + a.
     int32_t *env_fst;
     int32_t *env_rb;
     const float *psf;

@@ -414,10 +414,10 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     hzmax = -block_min_i32(-hzmax, scr32);
     __syncthreads();
     // ---- 6. envelope storage of the Hessian (BatchParams.env_fst / env_rb): first columns made non-decreasing and
-    //      multiples of 4 (the factorisation works on panels of 4 columns), row bases by a running sum ------------
+    //      multiples of SDSM_PANEL (the factorisation works on panels of that many columns), row bases by a running sum ------------
     if (tid == 0) {
         int run = M;
-        for (int a = M - 1; a >= 0; a--) { run = efirst[a] < run ? efirst[a] : run; efirst[a] = run & ~3; }
+        for (int a = M - 1; a >= 0; a--) { run = efirst[a] < run ? efirst[a] : run; efirst[a] = run & ~(SDSM_PANEL - 1); }
         int rp = 0;
         for (int a = 0; a < M; a++) {
             P.env_fst[cd.xi_off + a] = efirst[a];

@@ -63,7 +63,7 @@ struct Lay {
     static constexpr int W = NMAX + 2;             // vectors are indexed up to n (right-hand-side row) inclusive
     static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
     static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, IB = FLAG + 2;
-    static constexpr int NPANEL = NMAX / 4 + 2;
+    static constexpr int NPANEL = NMAX / SDSM_PANEL + 2;
     static constexpr int IB_DOUBLES = (2 * W + NPANEL + 1) / 2;      // int arrays: rb[W], fst[W], rend[NPANEL]
     static constexpr int HP = IB + IB_DOUBLES;
     static constexpr int END = HP + (GLOBALH ? 0 : EMAX);
@@ -672,7 +672,9 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
     //      entries are written after the barrier (nobody reads those columns again before the back substitution).
     //      WGS / SDSM_FACTOR_DIV threads take part (measured: 1 = all threads is fastest, 172 k vs 168 k (2) vs 156 k (4)
     //      candidate solves/s: the panel chain is latency bound, more threads = fewer serial entries per thread).
-    constexpr int NB = 4;
+    constexpr int NB = SDSM_PANEL;
+    constexpr int NBSH = NB == 8 ? 3 : 2;
+    static_assert(NB == 4 || NB == 8, "panel width");
     constexpr int FT = L::WGS / SDSM_FACTOR_DIV;                // threads that factor
     constexpr int GR = FT / 16;                                 // thread grid GR x 16 over the active rows x columns
     const int ri = tid >> 4, ki = tid & 15;
@@ -691,13 +693,13 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = n - j0 < NB ? n - j0 : NB;
         const int jn = j0 + nb;
-        const int re = j0 < M ? uni(rendp[j0 >> 2]) : M - 1;      // uniform: keep the panel's index arithmetic scalar
+        const int re = j0 < M ? uni(rendp[j0 >> NBSH]) : M - 1;      // uniform: keep the panel's index arithmetic scalar
         const int nxi = jn < M && re >= jn ? re - jn + 1 : 0;
         const int th0 = jn > M ? jn : M;
         const int na = nxi + (n - th0) + 1;
         double t[NB][NB], rinv[NB];
         if (fa) {
-        // A. diagonal block (rows j0 .. j0+3 all store column j0: fst is a multiple of 4)
+        // A. diagonal block (all rows of the panel store column j0: fst is a multiple of the panel width)
 #pragma unroll
         for (int a2 = 0; a2 < NB; a2++) {
             const int rba = a2 < nb ? uni(rbp[j0 + a2]) : 0;
@@ -721,7 +723,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
                 t[a2][cc] = v * r;
             }
         }
-        if (!ok && tid == 0) pflag[(j0 >> 2) & 1] = nonfinite ? 2 : 1;
+        if (!ok && tid == 0) pflag[(j0 >> NBSH) & 1] = nonfinite ? 2 : 1;
         // active rows below the panel: xi rows jn .. re, theta rows, right-hand side (compact index -> logical row)
         // B. rank-nb update of the active rows x active columns from the raw panel entries
         for (int ti = ri; ti < na; ti += GR) {
@@ -759,7 +761,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
         }
         }
         __syncthreads();
-        failed = pflag[(j0 >> 2) & 1];                         // uniform (two slots: a thread is at most one panel ahead)
+        failed = pflag[(j0 >> NBSH) & 1];                         // uniform (two slots: a thread is at most one panel ahead)
         if (failed) break;
         // C. factored block, reciprocal diagonal and solved panel entries (columns j0 .. j0+3: not read again before
         //    the back substitution, so the next panel starts without another barrier)
@@ -1041,9 +1043,9 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
                 for (int a = tid; a < M; a += L::WGS) { rbp[a] = P.env_rb[cd.xi_off + a]; fstp[a] = P.env_fst[cd.xi_off + a]; }
                 if (tid < 6) { rbp[M + tid] = exi + tid * M + tid * (tid + 1) / 2; fstp[M + tid] = 0; }
                 __syncthreads();
-                for (int pnl = tid; 4 * pnl < M; pnl += L::WGS) {                // last xi row whose envelope reaches column 4 pnl
-                    int lo = 4 * pnl, hi = M - 1;                                // fst is non-decreasing, fst[4 pnl] <= 4 pnl
-                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (fstp[mid] <= 4 * pnl) lo = mid; else hi = mid - 1; }
+                for (int pnl = tid; SDSM_PANEL * pnl < M; pnl += L::WGS) {      // last xi row whose envelope reaches the panel's first column
+                    int lo = SDSM_PANEL * pnl, hi = M - 1;                       // fst is non-decreasing, fst[first column] <= first column
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (fstp[mid] <= SDSM_PANEL * pnl) lo = mid; else hi = mid - 1; }
                     rendp[pnl] = lo;
                 }
                 c.env_size = efull;
