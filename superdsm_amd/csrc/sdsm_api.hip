@@ -191,8 +191,10 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
         c.ell_off = p->total_ell; p->total_ell += (int64_t)N * p->zcap;
         c.xi_off = p->total_xi; p->total_xi += c.Mcap;
         c.mask_off = p->total_mask_words; p->total_mask_words += ((int64_t)c.h * c.w + 31) / 32;
-        c.hsave_slot = -1;
-        c.hglob_slot = (6 + c.Mcap > SDSM_ENV_DENSE_N) ? (int32_t)p->n_hglob++ : -1;
+        if (6 + c.Mcap > SDSM_ENV_DENSE_N) {
+            const int64_t nn = 6 + std::min<int64_t>(c.Mcap, SDSM_MAX_N_SOLVE - 6);
+            c.hglob_off = p->n_hglob; p->n_hglob += nn * (nn + 1) / 2;
+        } else c.hglob_off = -1;
         c.pad = 0;
         c.perm_inv = perm_inverse((uint32_t)std::max<long>(N, 1));
         p->mask_info[4 * i] = r0; p->mask_info[4 * i + 1] = c0; p->mask_info[4 * i + 2] = c.h; p->mask_info[4 * i + 3] = c.w;
@@ -226,7 +228,7 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
     p->off_env_fst = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
-    p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1) * (SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2));
+    p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1));      // n_hglob counts doubles
     p->total = o;
     return p;
 }
@@ -342,7 +344,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.hess_thr = SDSM_HESS_THR;
     P.psf = (const float *)(b + p->off_psf);
     P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
-    P.hglob = (double *)(b + p->off_hglob); P.hglob_stride = SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2;
+    P.hglob = (double *)(b + p->off_hglob);
     P.prof = g_prof;
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");

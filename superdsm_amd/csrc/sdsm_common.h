@@ -57,10 +57,9 @@ struct CandDesc {
     int32_t r0, c0, h, w;   // region bounding box (union of the atoms' valid extents)
     int32_t fp_off, fp_len; // footprint labels
     int32_t Mcap;       // upper bound of M
-    int32_t hsave_slot; // unused (-1)
     uint32_t perm_inv;  // crop position of the pixel with raster rank i is (i * perm_inv) mod N (low-discrepancy scatter)
-    int32_t hglob_slot; // slot in the global Hessian pool of the class whose envelope does not fit LDS (only possible if 6 + Mcap > SDSM_ENV_DENSE_N), else -1
     int32_t pad;
+    int64_t hglob_off;  // first double of its block in the global Hessian pool (a dense triangle of 6 + min(Mcap, 1018) unknowns; only if 6 + Mcap > SDSM_ENV_DENSE_N: the envelope may not fit LDS), else -1
 };
 
 // Written by the setup kernel.
@@ -109,8 +108,7 @@ struct BatchParams {
     int32_t *env_fst;
     int32_t *env_rb;
     const float *psf;
-    double *hglob;                     // per-candidate Hessian of the global-memory class (envelope too large for LDS)
-    int64_t hglob_stride;
+    double *hglob;                     // Hessian pool of the global-memory class (envelope too large for LDS), CandDesc.hglob_off
     long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 8 cycle counters per candidate
 };
 

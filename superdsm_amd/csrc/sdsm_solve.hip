@@ -966,7 +966,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     const int efull = Mfull > 0 ? st.env_size : 21;
     if (nfull <= nprev && efull <= eprev && cd.N <= pixprev) return;         // an earlier class took it
     if (!(nfull <= NMAX && efull <= EMAX && cd.N <= pixmax)) return;         // a later class takes it
-    if (GLOBALH && cd.hglob_slot < 0) {                          // cannot happen (the host reserves a slot whenever Mcap admits it)
+    if (GLOBALH && cd.hglob_off < 0) {                          // cannot happen (the host reserves a slot whenever Mcap admits it)
         if (tid == 0) { sdsm_record r0 = {}; r0.status = SDSM_CAND_UNSUPPORTED; r0.n_pixels = cd.N; r0.n_deform = st.M; *rec = r0; }
         return;
     }
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = Mfull > 0 ? st.gcount[j] : 0;
-    c.hglob = (GLOBALH && cd.hglob_slot >= 0) ? P.hglob + (int64_t)cd.hglob_slot * P.hglob_stride : nullptr;
+    c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
     c.epsilon = P.epsilon; c.alpha = P.alpha;
     // local frame: centre of the bounding box, half extents

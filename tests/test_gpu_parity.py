@@ -447,3 +447,36 @@ def test_latency_mode_gives_the_same_results(gpu):
     np.testing.assert_allclose(r1['energy'], r0['energy'], rtol=1e-6, atol=1e-9)
     for a, b in zip(f0, f1):
         assert testing.dice(a[0], a[1], b[0], b[1], scene['y'].shape) >= 0.999
+
+
+def test_wide_envelope_and_long_rows_use_the_global_memory_class(gpu):
+    """A dense grid (smooth_subsample 3): G~ rows of ~100 entries (the generic row path, not the 28-entry register
+    path) and a Hessian envelope far beyond the LDS classes (class 3: envelope in global memory)."""
+    from oracle import oracle
+    from superdsm_amd import engine
+    rng = np.random.default_rng(11)
+    H, W = 110, 120
+    rr, cc = np.mgrid[:H, :W]
+    y = -0.15 + 0.03 * rng.standard_normal((H, W))
+    blob = ((rr - 55) / 30.0) ** 2 + ((cc - 60) / 36.0) ** 2
+    y += 0.5 * np.exp(-1.5 * blob)
+    y += 0.25 * np.exp(-(((rr - 40) / 9.0) ** 2 + ((cc - 85) / 7.0) ** 2))       # a bump the ellipse cannot follow
+    atoms = np.ones((H, W), np.int32)
+    cfg = dict(scale=1000, epsilon=1.0, alpha=0.05, smooth_amount=4, smooth_subsample=3, gaussian_shape_multiplier=2,
+               background_margin=6, init='elliptical')
+    img = engine.DeviceImage(y, None, atoms, cfg['background_margin'])
+    batch = engine.Batch(img, [[1]], cfg)
+    batch.launch()
+    gpu.cuda.synchronize()
+    rec = batch.records()[0]
+    ins = batch.inspect()[0]
+    orecs, ofrags, _ = oracle.compute_objects(y, None, atoms, [[1]], cfg, nthreads=0)
+    n = 6 + int(rec['n_deform'])
+    assert ins['zmax'] > 28, 'rows must exceed the register path'
+    assert 152 < n <= 1024 and int(ins['env_size']) > 11000, 'the envelope must exceed the LDS classes'
+    assert rec['status'] == orecs['status'][0] == 0 and rec['n_deform'] == orecs['M'][0]
+    tol = 1e-6 * orecs['N'][0] / 1000 + 1e-5 * abs(orecs['energy'][0])
+    assert abs(rec['energy'] - orecs['energy'][0]) <= tol
+    frag = batch.fragments(batch.records())[0]
+    from superdsm_amd import testing
+    assert testing.dice(frag[0], frag[1], orecs['fg_offset'][0], ofrags[0], (H, W)) >= 0.999
