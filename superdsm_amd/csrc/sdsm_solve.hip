@@ -216,24 +216,31 @@ __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, dou
 // rows are zero-padded to the group count of the first position of their 64-position chunk, so group j is fetched by a
 // wavefront iff its first position needs it: a uniform test against CandState.gcount, one 16-byte + one 8-byte load per
 // lane and group, all issued before the first use.
-__device__ __forceinline__ void load_row(const Cand &c, int p, float (&w)[ZREG], int (&id)[ZREG])
+// Column indices of a row stay packed two per register (as loaded); RID(ip, s) with a compile-time s is a shift or a mask.
+typedef unsigned RowIds[ZREG / 2];
+#define RID(ip, s) (((s) & 1) ? (int)((ip)[(s) >> 1] >> 16) : (int)((ip)[(s) >> 1] & 0xffffu))
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef const u32x2 SDSM_GLOBAL *g_cu32x2_p;
+
+__device__ __forceinline__ void load_row(const Cand &c, int p, float (&w)[ZREG], RowIds &ip)
 {
     const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
         if (q0 < c.gcount[j]) {
             const f32x4 wv = c.ell_w4[(size_t)j * c.N + p];
-            const u16x4 iv = c.ell_i4[(size_t)j * c.N + p];
+            const u32x2 iv = ((g_cu32x2_p)c.ell_i4)[(size_t)j * c.N + p];
             w[4 * j] = wv.x; w[4 * j + 1] = wv.y; w[4 * j + 2] = wv.z; w[4 * j + 3] = wv.w;
-            id[4 * j] = iv.x; id[4 * j + 1] = iv.y; id[4 * j + 2] = iv.z; id[4 * j + 3] = iv.w;
+            ip[2 * j] = iv.x; ip[2 * j + 1] = iv.y;
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) { w[4 * j + k] = 0.f; id[4 * j + k] = 0; }
+            for (int k = 0; k < 4; k++) w[4 * j + k] = 0.f;
+            ip[2 * j] = 0; ip[2 * j + 1] = 0;
         }
     }
 }
 
-__device__ __forceinline__ double gather_row(const Cand &c, const double *xv, int p, const float (&w)[ZREG], const int (&id)[ZREG])
+__device__ __forceinline__ double gather_row(const Cand &c, const double *xv, int p, const float (&w)[ZREG], const RowIds &ip)
 {
     const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
     double gx = 0;
@@ -241,7 +248,7 @@ __device__ __forceinline__ double gather_row(const Cand &c, const double *xv, in
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
         if (q0 < c.gcount[j]) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) gx += (double)w[4 * j + k] * xv[6 + id[4 * j + k]];
+            for (int k = 0; k < 4; k++) gx += (double)w[4 * j + k] * xv[6 + RID(ip, 4 * j + k)];
         }
     }
     return gx;
@@ -255,9 +262,9 @@ __device__ __forceinline__ int ell_i_at(const Cand &c, int s, int p) { return ((
 __device__ __forceinline__ double smooth_term(const Cand &c, const double *xv, int p)
 {
     if (c.zmax <= ZREG) {
-        float w[ZREG]; int id[ZREG];
-        load_row(c, p, w, id);
-        return gather_row(c, xv, p, w, id);
+        float w[ZREG]; RowIds ip;
+        load_row(c, p, w, ip);
+        return gather_row(c, xv, p, w, ip);
     }
     const int nnz = (int)(c.ell_meta[p] & 0xffffu);
     double gx = 0;
@@ -321,8 +328,8 @@ __device__ __noinline__ void eval_line(const Cand &c_in, int M_in, double t0_in,
         double Sd = q0 * xd[1] + q1 * xd[3] + q2 * xd[5] + q3 * xd[7] + q4 * xd[9] + xd[11];
         if (M > 0) {
             if (in_regs) {
-                float w[ZREG]; int id[ZREG];
-                load_row(c, p, w, id);
+                float w[ZREG]; RowIds ip;
+                load_row(c, p, w, ip);
                 const int q0g = __builtin_amdgcn_readfirstlane(p) & ~63;
 #pragma unroll
                 for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
@@ -330,7 +337,7 @@ __device__ __noinline__ void eval_line(const Cand &c_in, int M_in, double t0_in,
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const double wv = (double)w[4 * j + k];
-                            const double *pr = xd + 2 * (6 + id[4 * j + k]);
+                            const double *pr = xd + 2 * (6 + RID(ip, 4 * j + k));
                             S0 += wv * pr[0]; Sd += wv * pr[1];
                         }
                     }
@@ -467,11 +474,11 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M_in PROF_
         double Sv = q[0] * xv[0] + q[1] * xv[1] + q[2] * xv[2] + q[3] * xv[3] + q[4] * xv[4] + xv[5];
         const uint32_t meta = M > 0 ? c.ell_meta[p] : 0u;
         const int nnz = (int)(meta & 0xffffu);
-        float w[ZREG]; int id[ZREG];
+        float w[ZREG]; RowIds ip;
         if (in_regs) {
-            load_row(c, p, w, id);
+            load_row(c, p, w, ip);
             FINE_ADD(8);
-            Sv += gather_row(c, xv, p, w, id);
+            Sv += gather_row(c, xv, p, w, ip);
         } else if (M > 0) Sv += smooth_term(c, xv, p);
         FINE_ADD(9);
         double phi, r, dc;
@@ -488,28 +495,32 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M_in PROF_
             const int hnz = (int)(meta >> 16);
             if (in_regs) {
                 const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
+                // the weights are converted to double again here (and below): keeping the 28 converted values of the
+                // gather alive across the loss costs 56 registers, a conversion costs one instruction
+#pragma unroll
+                for (int s2 = 0; s2 < ZREG; s2++) asm volatile("" : "+v"(w[s2]));
 #pragma unroll
                 for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
                     if (q0 < c.gcount[j]) {
 #pragma unroll
                         for (int k = 0; k < 4; k++)
-                            if (4 * j + k < nnz) atomicAdd(&g[6 + id[4 * j + k]], r * (double)w[4 * j + k]);   // exact gradient: every entry
+                            if (4 * j + k < nnz) atomicAdd(&g[6 + RID(ip, 4 * j + k)], r * (double)w[4 * j + k]);   // exact gradient: every entry
                     }
                 }
                 FINE_ADD(11);
                 if (c.hzmax <= HZREG) {
                     int rbs[HZREG];                                                      // row bases of the leading entries
 #pragma unroll
-                    for (int a = 0; a < HZREG; a++) rbs[a] = a < hnz ? rbp[id[a]] : 0;
+                    for (int a = 0; a < HZREG; a++) rbs[a] = a < hnz ? rbp[RID(ip, a)] : 0;
 #pragma unroll
                     for (int a = 0; a < HZREG; a++) {                                    // approximate Hessian: leading entries
                         if (a < hnz) {
                             const double dwa = dc * (double)w[a];
-                            const int ia = id[a];
+                            const int ia = RID(ip, a);
 #pragma unroll
                             for (int b = 0; b < 6; b++) atomicAdd(&Hp[rbt[b] + ia], dwa * q[b]);      // theta rows, column xi_ia
 #pragma unroll
-                            for (int b = 0; b <= a; b++) atomicAdd(&Hp[rbs[a] + id[b]], dwa * (double)w[b]);   // leading entries are in ascending column order
+                            for (int b = 0; b <= a; b++) atomicAdd(&Hp[rbs[a] + RID(ip, b)], dwa * (double)w[b]);   // leading entries are in ascending column order
                         }
                     }
                 } else {
