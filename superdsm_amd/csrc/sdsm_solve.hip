@@ -687,8 +687,6 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
     constexpr int NBSH = NB == 8 ? 3 : 2;
     static_assert(NB == 4 || NB == 8, "panel width");
     constexpr int FT = L::WGS / SDSM_FACTOR_DIV;                // threads that factor
-    constexpr int GR = FT / 16;                                 // thread grid GR x 16 over the active rows x columns
-    const int ri = tid >> 4, ki = tid & 15;
     const bool fa = tid < FT;
     int *pflag = (int *)(SD + L::FLAG);                         // [2]: panel p reports a failed pivot in slot p & 1
     for (int i = tid; i < n; i += L::WGS) {
@@ -736,39 +734,36 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
         }
         if (!ok && tid == 0) pflag[(j0 >> NBSH) & 1] = nonfinite ? 2 : 1;
         // active rows below the panel: xi rows jn .. re, theta rows, right-hand side (compact index -> logical row)
-        // B. rank-nb update of the active rows x active columns from the raw panel entries
-        for (int ti = ri; ti < na; ti += GR) {
+        // B. rank-nb update of the active rows x active columns from the raw panel entries.  The (row, column) pairs --
+        //    a triangle over the active rows plus the right-hand-side row -- are dealt to the threads by a flat index, so
+        //    that every wavefront gets the same share (a panel has ~400 pairs: 1-2 per thread).
+        const int ntri = (na - 1) * na / 2, npair = ntri + (na - 1);
+        for (int e = tid; e < npair; e += FT) {
+            int ti, tk;
+            if (e < ntri) {
+                ti = (int)((__fsqrt_rn(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                ti += (ti + 1) * (ti + 2) / 2 <= e ? 1 : 0;                // float rounding: at most one off, either way
+                ti -= ti * (ti + 1) / 2 > e ? 1 : 0;
+                tk = e - ti * (ti + 1) / 2;
+            } else { ti = na - 1; tk = e - ntri; }
             const int i = ti < nxi ? jn + ti : th0 + (ti - nxi);          // == n for the right-hand side
+            const int k = tk < nxi ? jn + tk : th0 + (tk - nxi);
             const double *pi = i < n ? Hp + rbp[i] + j0 : yrow + j0;
-            double li[NB];
+            const double *pk = Hp + rbp[k] + j0;
+            double li[NB], lk[NB];
 #pragma unroll
-            for (int cc = 0; cc < NB; cc++) li[cc] = cc < nb ? pi[cc] : 0.0;
+            for (int cc = 0; cc < NB; cc++) { li[cc] = cc < nb ? pi[cc] : 0.0; lk[cc] = cc < nb ? pk[cc] : 0.0; }
+            double *Lik = (i < n ? Hp + rbp[i] : yrow) + k;
+            double acc = *Lik;
 #pragma unroll
             for (int cc = 0; cc < NB; cc++) {
-                double acc = li[cc];
+                double a3 = li[cc], b3 = lk[cc];
 #pragma unroll
-                for (int m = 0; m < cc; m++) acc -= li[m] * t[cc][m];
-                li[cc] = acc * rinv[cc];
+                for (int m = 0; m < cc; m++) { a3 -= li[m] * t[cc][m]; b3 -= lk[m] * t[cc][m]; }
+                li[cc] = a3 * rinv[cc]; lk[cc] = b3 * rinv[cc];
+                acc -= li[cc] * lk[cc];
             }
-            double *Li = i < n ? Hp + rbp[i] : yrow;
-            const int tkend = ti < na - 1 ? ti : na - 2;                  // columns: active rows except the right-hand side
-            for (int tk = ki; tk <= tkend; tk += 16) {
-                const int k = tk < nxi ? jn + tk : th0 + (tk - nxi);
-                const double *pk = Hp + rbp[k] + j0;
-                double lk[NB];
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) lk[cc] = cc < nb ? pk[cc] : 0.0;
-                double acc = Li[k];
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) {
-                    double a3 = lk[cc];
-#pragma unroll
-                    for (int m = 0; m < cc; m++) a3 -= lk[m] * t[cc][m];
-                    lk[cc] = a3 * rinv[cc];
-                    acc -= li[cc] * lk[cc];
-                }
-                Li[k] = acc;
-            }
+            *Lik = acc;
         }
         }
         __syncthreads();
