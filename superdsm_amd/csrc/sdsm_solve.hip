@@ -732,6 +732,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
                 t[a2][cc] = v * r;
             }
         }
+        PROF_ADD(8, pf);
         if (!ok && tid == 0) pflag[(j0 >> NBSH) & 1] = nonfinite ? 2 : 1;
         // active rows below the panel: xi rows jn .. re, theta rows, right-hand side (compact index -> logical row)
         // B. rank-nb update of the active rows x active columns from the raw panel entries.  The (row, column) pairs --
@@ -766,13 +767,16 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
             *Lik = acc;
         }
         }
+        PROF_ADD(9, pf);
         __syncthreads();
+        PROF_ADD(10, pf);
         failed = pflag[(j0 >> NBSH) & 1];                         // uniform (two slots: a thread is at most one panel ahead)
         if (failed) break;
         // C. factored block, reciprocal diagonal and solved panel entries (columns j0 .. j0+3: not read again before
         //    the back substitution, so the next panel starts without another barrier)
-        if (tid < NB * NB) {
-            const int a2 = tid / NB, b2 = tid % NB;
+        // (done by the LAST wavefronts: the flat pair index gives the low threads the second round of step B)
+        if (tid >= FT - 64 - NB * NB && tid < FT - 64) {
+            const int a2 = (tid - (FT - 64 - NB * NB)) / NB, b2 = (tid - (FT - 64 - NB * NB)) % NB;
             if (b2 <= a2 && a2 < nb) {
                 double v = 0, rv = 0;
 #pragma unroll
@@ -785,7 +789,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
                 if (a2 == b2) dg[j0 + a2] = rv;
             }
         }
-        if (fa) for (int tt = tid; tt < na; tt += FT) {
+        if (fa) for (int tt = tid - (FT - 64); tt >= 0 && tt < na; tt += 64) {
             const int i = tt < nxi ? jn + tt : th0 + (tt - nxi);
             double *row = i < n ? Hp + rbp[i] + j0 : yrow + j0;
             double v[NB];
@@ -801,6 +805,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
 #pragma unroll
             for (int cc = 0; cc < NB; cc++) if (cc < nb) row[cc] = v[cc];
         }
+        PROF_ADD(11, pf);
     }
     __syncthreads();
     PROF_ADD(14, pf);

@@ -44,6 +44,10 @@ if p[:, 8:13].sum() > 0:
 if p[:, 13:16].sum() > 0:
     m = cls == 'B'
     print('factor_solve parts, class B, us per call (median): head %.1f  panels %.1f  l2 + back substitution %.1f' % tuple(np.median(p[m, 13 + i] / np.maximum(recs['iters_dsm'][m], 1)) / 2400 for i in range(3)))
+if p[:, 8:12].sum() > 0 and p[:, 13:16].sum() > 0:
+    m = cls == 'B'
+    tot = p[m, 8:12].sum()
+    print('panel loop of the factorisation, class B, thread 0: diagonal block %.1f%%  trailing update %.1f%%  barrier wait %.1f%%  write-back %.1f%%' % tuple(100 * p[m, 8 + i].sum() / tot for i in range(4)))
 print('slowest candidates:')
 for k in worst:
     print('  cand %d N=%d M=%d it_ell=%d it_dsm=%d evals=%d/%d total=%.2f ms  A=%.2f B=%.2f red=%.2f fac=%.2f ls=%.2f' % (
