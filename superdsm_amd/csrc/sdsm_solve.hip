@@ -151,12 +151,13 @@ __device__ __forceinline__ double exp_neg(double a)
     return ldexp(p, -(int)kf);
 }
 
-__device__ __forceinline__ double rcp_f64(double x)        // 1 / x, x in the normal range
+// 1 / x, x in the normal range: hardware estimate (4.6e-8 relative, tools/microbench/rsq_accuracy.hip) + ONE Newton step =
+// 2.2e-15 relative (20 ulp); a second step would give 1 ulp.  Enough here: log_1_2 corrects its quotient with a residual
+// step, and theta only needs the accuracy of the gradient.
+__device__ __forceinline__ double rcp_f64(double x)
 {
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return y;
+    const double y = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, y, 1.0), y, y);
 }
 
 // log(w) for 1 <= w <= 2: w = 2^e m with m in (sqrt(1/2), sqrt(2)], log m = 2 atanh((m - 1) / (m + 1)), 1.3e-16 absolute
@@ -566,16 +567,14 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M_in PROF_
     return psi;
 }
 
-// 1 / sqrt(x) to double precision: hardware estimate + two Newton steps (x in the normal range)
+// 1 / sqrt(x), x in the normal range: hardware estimate (5.2e-8 relative) + ONE Newton step = 4.2e-15 relative (37 ulp,
+// tools/microbench/rsq_accuracy.hip).  The pivots of the Cholesky factorisation sit on its dependent chain, and a factor of
+// an approximate Hessian does not need the last bits.
 __device__ __forceinline__ double rsqrt_f64(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    const double h = 0.5 * x;
-    double e = fma(-h * y, y, 0.5);
-    y = fma(y, e, y);
-    e = fma(-h * y, y, 0.5);
-    y = fma(y, e, y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-0.5 * x * y, y, 0.5);
+    return fma(y, e, y);
 }
 
 // ---------------------------------------------------------------------------------------------------------
