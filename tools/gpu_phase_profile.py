@@ -43,7 +43,7 @@ if p[:, 8:13].sum() > 0:
     print('fine sections of the sparse pixel pass (thread 0, fenced): loads %.1f%%  gather %.1f%%  loss+sums %.1f%%  grad atomics %.1f%%  hess atomics %.1f%%' % tuple(100 * p[:, 8:13].sum(0) / p[:, 8:13].sum()))
 if p[:, 13:16].sum() > 0:
     m = cls == 'B'
-    print('factor_solve parts, class B, us per call (median): head %.1f  panels %.1f  l2 + back substitution %.1f' % tuple(np.median(p[m, 13 + i] / np.maximum(recs['iters_dsm'][m], 1)) / 2400 for i in range(3)))
+    print('factor_solve parts, class B, us per call (median): head %.1f  panels %.1f  l2 + back substitution %.1f' % (np.median(p[m, 13] / np.maximum(recs['iters_dsm'][m], 1)) / 2400, np.median((p[m, 8:12].sum(1) + p[m, 14]) / np.maximum(recs['iters_dsm'][m], 1)) / 2400, np.median(p[m, 15] / np.maximum(recs['iters_dsm'][m], 1)) / 2400))
 if p[:, 8:12].sum() > 0 and p[:, 13:16].sum() > 0:
     m = cls == 'B'
     tot = p[m, 8:12].sum()
