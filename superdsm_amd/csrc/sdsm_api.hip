@@ -123,7 +123,7 @@ struct sdsm_plan {
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
     int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hsave = 0, n_hglob = 0;
-    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_ell_meta = 0,
+    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_ell_meta = 0,
            off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, total = 0;
 };
 
@@ -222,6 +222,7 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->off_dist = take(4 * np);
     p->off_tmp_y = take(8 * np);
     p->off_tmp_rc = take(4 * np);
+    p->off_inv = take(4 * np);
     p->off_ell_meta = take(4 * np);
     p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
@@ -337,7 +338,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);
     P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
     P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_meta = (uint32_t *)(b + p->off_ell_meta);
-    P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc);
+    P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc); P.inv = (uint32_t *)(b + p->off_inv);
 #ifndef SDSM_HESS_THR
 #define SDSM_HESS_THR 0.1f    // same constant as the oracle's ORC_HESS_THR
 #endif

@@ -95,6 +95,7 @@ struct BatchParams {
     uint32_t *tmp_rc;                  // setup only
     uint32_t *crop_cc;                 // compressed coordinates (setup only, scan order)
     uint32_t *dist;                    // setup only: chessboard distance to the nearest grid point, then the final crop position
+    uint32_t *inv;                     // setup only: scan-order index of a final crop position
     uint32_t *grid_rc;                 // sorted grid points, compressed coordinates
     // G~ rows: entry s of the row of crop position p is element ((s / 4) * N + p) * 4 + s % 4 of the candidate's block:
     // one 16-byte (weights) + one 8-byte (column indices) load per lane fetches 4 entries, consecutive lanes read

@@ -327,7 +327,9 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             if (k >= 0) {
                 int before = 0;
                 for (int w2 = 0; w2 < wave; w2++) before += wave_cnt[w2][k];
-                P.dist[cd.crop_off + i] = (uint32_t)(cls_start[k] + cls_run[k] + before + within);
+                const uint32_t np2 = (uint32_t)(cls_start[k] + cls_run[k] + before + within);
+                P.dist[cd.crop_off + i] = np2;
+                P.inv[cd.crop_off + np2] = (uint32_t)i;
             }
             __syncthreads();
             for (int k2 = tid; k2 <= ngmax; k2 += SDSM_WG) {
@@ -345,8 +347,8 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     // ---- 5. rows of G~: PSF gather, float32 pairwise row sum, float32 division (dsm.py:192-193) --
     bool bad = false;
     int zmax = 0, hzmax = 0;
-    for (int i = tid; i < cd.N; i += SDSM_WG) {
-        const int pos = (int)P.dist[cd.crop_off + i];
+    for (int pos = tid; pos < cd.N; pos += SDSM_WG) {     // in final crop order: neighbouring lanes write neighbouring rows
+        const int i = (int)P.inv[cd.crop_off + pos];
         uint32_t key = P.crop_cc[cd.crop_off + i];
         WeightCtx c;
         c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.keys = gridkeys;
