@@ -17,11 +17,9 @@ struct WeightCtx {
     int cr, cc, R, k;
     const float *psf;
     const uint32_t *keys;   // sorted grid keys in LDS
-    uint16_t *ell_idx;
-    float *ell_w;
-    int64_t base;           // ell_off + 4 * crop position
-    int N, zcap, nnz;
-    bool overflow;
+    int jlo, jhi;           // grid points whose (compressed) row lies within R of the pixel's: the only ones that can be in the window
+    int nnz;                // entries of the row (grid points inside the PSF window)
+    float wmax;             // largest of them
 };
 
 // entry s of the row whose group-0 element starts at base (= ell_off + 4 * position)
@@ -34,34 +32,34 @@ __device__ __forceinline__ float wval(WeightCtx &c, int j)
     int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
     if (adr <= c.R && adc <= c.R) {
         float v = c.psf[(c.R + dr) * c.k + (c.R + dc)];
-        if (c.nnz < c.zcap) {
-            const int64_t e = ell_at(c.base, c.N, c.nnz);
-            c.ell_idx[e] = (uint16_t)j;
-            c.ell_w[e] = v;
-        } else c.overflow = true;
+        c.wmax = v > c.wmax ? v : c.wmax;
         c.nnz++;
         return v;
     }
     return 0.f;
 }
 
-// numpy's pairwise float32 sum of one block of <= 128 elements (loops_utils.h.src)
+// numpy's pairwise float32 sum of one block of <= 128 elements (loops_utils.h.src).  Only the grid points j in
+// [c.jlo, c.jhi) can be non-zero; the others are skipped, which changes nothing: an element is added to accumulator
+// (j - lo) % 8 in the order of j as numpy does, and adding +0.0f is exact.
 __device__ float pw_block(WeightCtx &c, int lo, int n)
 {
+    const int a = lo > c.jlo ? lo : c.jlo, b = lo + n < c.jhi ? lo + n : c.jhi;
+    if (a >= b) return 0.f;
     if (n < 8) {
         float res = 0.f;
-        for (int i = 0; i < n; i++) res += wval(c, lo + i);
+        for (int j = a; j < b; j++) res += wval(c, j);
         return res;
     }
-    float r0 = wval(c, lo), r1 = wval(c, lo + 1), r2 = wval(c, lo + 2), r3 = wval(c, lo + 3);
-    float r4 = wval(c, lo + 4), r5 = wval(c, lo + 5), r6 = wval(c, lo + 6), r7 = wval(c, lo + 7);
-    int nfull = n - (n % 8), i;
-    for (i = 8; i < nfull; i += 8) {
-        r0 += wval(c, lo + i); r1 += wval(c, lo + i + 1); r2 += wval(c, lo + i + 2); r3 += wval(c, lo + i + 3);
-        r4 += wval(c, lo + i + 4); r5 += wval(c, lo + i + 5); r6 += wval(c, lo + i + 6); r7 += wval(c, lo + i + 7);
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f, r5 = 0.f, r6 = 0.f, r7 = 0.f;
+    const int nfull = n - (n % 8);
+    const int bend = lo + nfull < b ? lo + nfull : b;
+    for (int base = lo + ((a - lo) & ~7); base < bend; base += 8) {
+        r0 += wval(c, base); r1 += wval(c, base + 1); r2 += wval(c, base + 2); r3 += wval(c, base + 3);
+        r4 += wval(c, base + 4); r5 += wval(c, base + 5); r6 += wval(c, base + 6); r7 += wval(c, base + 7);
     }
     float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += wval(c, lo + i);
+    for (int j = lo + nfull > a ? lo + nfull : a; j < b; j++) res += wval(c, j);
     return res;
 }
 
@@ -277,6 +275,15 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     __syncthreads();
     for (int j = tid; j < M; j += SDSM_WG) gridkeys[j] = P.grid_rc[cd.xi_off + j];
     __syncthreads();
+    // first grid point of every compressed row (the row / column rank tables are no longer needed: reuse rowrank): a pixel
+    // only looks at the grid points of the rows within R of its own
+    uint16_t *growstart = rowrank;
+    for (int r = tid; r < hc && r < SDSM_MAX_BBOX_DIM; r += SDSM_WG) {
+        int lo = 0, hi = M;                               // first j with row(j) >= r
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(gridkeys[mid] >> 16) < r) lo = mid + 1; else hi = mid; }
+        growstart[r] = (uint16_t)lo;
+    }
+    __syncthreads();
 
     // ---- 4b. final crop order: stable counting sort of the scan order by the number of 4-entry groups of the pixel's
     //      G~ row, largest first.  A wavefront of the solve kernel then reads 64 rows of (nearly) the same length and
@@ -288,7 +295,8 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         uint32_t key = P.crop_cc[cd.crop_off + i];
         const int cr = key >> 16, cc = key & 0xffffu;
         int cnt = 0;
-        for (int j = 0; j < M; j++) {
+        const int jlo = growstart[cr - R > 0 ? cr - R : 0], jhi = cr + R + 1 < hc ? growstart[cr + R + 1] : M;
+        for (int j = jlo; j < jhi; j++) {
             int dr = (int)(gridkeys[j] >> 16) - cr, dc = (int)(gridkeys[j] & 0xffffu) - cc;
             dr = dr < 0 ? -dr : dr; dc = dc < 0 ? -dc : dc;
             cnt += (dr <= R && dc <= R) ? 1 : 0;
@@ -350,62 +358,42 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     for (int pos = tid; pos < cd.N; pos += SDSM_WG) {     // in final crop order: neighbouring lanes write neighbouring rows
         const int i = (int)P.inv[cd.crop_off + pos];
         uint32_t key = P.crop_cc[cd.crop_off + i];
+        // pass 1 over the grid points: row sum in numpy's order, largest entry, number of entries (nothing is stored)
         WeightCtx c;
-        c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.keys = gridkeys;
-        c.ell_idx = P.ell_idx; c.ell_w = P.ell_w; c.base = cd.ell_off + (int64_t)pos * 4; c.N = cd.N; c.zcap = P.zcap; c.nnz = 0; c.overflow = false;
+        c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.keys = gridkeys; c.nnz = 0; c.wmax = 0.f;
+        c.jlo = growstart[c.cr - R > 0 ? c.cr - R : 0]; c.jhi = c.cr + R + 1 < hc ? growstart[c.cr + R + 1] : M;
+        const int64_t base = cd.ell_off + (int64_t)pos * 4;
         P.crop_y[cd.crop_off + pos] = P.tmp_y[cd.crop_off + i];
         P.crop_rc[cd.crop_off + pos] = P.tmp_rc[cd.crop_off + i];
-        float sum = pw_sum(c, M);
-        if (c.overflow || !(sum > 0.f)) { bad = true; P.ell_meta[cd.crop_off + pos] = 0; continue; }   // dsm.py:194
-        for (int sl = 0; sl < c.nnz; sl++) {
-            const int64_t e = ell_at(c.base, cd.N, sl);
-            P.ell_w[e] = __fdiv_rn(P.ell_w[e], sum);
+        const float sum = pw_sum(c, M);
+        if (c.nnz > P.zcap || !(sum > 0.f)) { bad = true; P.ell_meta[cd.crop_off + pos] = 0; continue; }   // dsm.py:194
+        // pass 2: normalised entries written once, straight into their final slots: entries >= hess_thr * row maximum (the
+        // solver's approximate Hessian uses only those; S and the gradient use all) from slot 0 upwards -- in ascending
+        // column order, so the solve kernel knows which of a pair is the row --, the others from slot nnz - 1 downwards
+        const float lim = P.hess_thr * __fdiv_rn(c.wmax, sum);
+        int hz = 0, others = 0, mn = 0;
+        for (int j = c.jlo; j < c.jhi; j++) {
+            const uint32_t gk = gridkeys[j];
+            int dr = (int)(gk >> 16) - c.cr, dc = (int)(gk & 0xffffu) - c.cc;
+            const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
+            if (adr > R || adc > R) continue;
+            const float nw = __fdiv_rn(P.psf[(R + dr) * P.k + (R + dc)], sum);
+            int slot;
+            if (!(nw < lim)) {
+                slot = hz++;
+                // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
+                if (slot == 0) mn = j; else atomicMin(&efirst[j], mn);
+            } else slot = c.nnz - 1 - others++;
+            const int64_t e = ell_at(base, cd.N, slot);
+            P.ell_idx[e] = (uint16_t)j; P.ell_w[e] = nw;
         }
         // padding (index 0, weight 0) up to the group count of the first position of this pixel's 64-position chunk: a
         // wavefront of the solve kernel reads the groups its first lane needs for all of its lanes
         int kh = 0;
         { const int head = pos & ~63; for (int k2 = ngmax; k2 >= 0; k2--) if (cls_cnt[k2] > 0 && head >= cls_start[k2]) kh = k2; }
         for (int sl = c.nnz; sl < 4 * kh; sl++) {
-            const int64_t e = ell_at(c.base, cd.N, sl);
+            const int64_t e = ell_at(base, cd.N, sl);
             P.ell_idx[e] = 0; P.ell_w[e] = 0.f;
-        }
-        // Partition the row: entries >= hess_thr * row maximum first (the solver's approximate Hessian uses only those;
-        // S and the gradient use all).  Two-pointer swap, O(nnz); the order inside the two parts is irrelevant.
-        int hz = 0;
-        if (c.nnz > 0) {
-            float wmax = 0.f;
-            for (int a = 0; a < c.nnz; a++) { float w2 = P.ell_w[ell_at(c.base, cd.N, a)]; wmax = w2 > wmax ? w2 : wmax; }
-            const float lim = P.hess_thr * wmax;
-            int lo = 0, hi = c.nnz - 1;
-            while (lo <= hi) {
-                const int64_t el = ell_at(c.base, cd.N, lo);
-                const float wl = P.ell_w[el];
-                if (!(wl < lim)) { lo++; continue; }
-                const int64_t eh = ell_at(c.base, cd.N, hi);
-                const float wh = P.ell_w[eh];
-                if (wh < lim) { hi--; continue; }
-                const uint16_t il = P.ell_idx[el], ih = P.ell_idx[eh];
-                P.ell_w[el] = wh; P.ell_idx[el] = ih;
-                P.ell_w[eh] = wl; P.ell_idx[eh] = il;
-                lo++; hi--;
-            }
-            hz = lo;
-            // the Hessian entries in ascending column order (the solve kernel then knows which of a pair is the row)
-            for (int a = 1; a < hz; a++) {
-                const int64_t ea = ell_at(c.base, cd.N, a);
-                const uint16_t ia = P.ell_idx[ea]; const float wa = P.ell_w[ea];
-                int b = a - 1;
-                while (b >= 0 && P.ell_idx[ell_at(c.base, cd.N, b)] > ia) {
-                    const int64_t eb = ell_at(c.base, cd.N, b), eb1 = ell_at(c.base, cd.N, b + 1);
-                    P.ell_idx[eb1] = P.ell_idx[eb]; P.ell_w[eb1] = P.ell_w[eb];
-                    b--;
-                }
-                const int64_t eb1 = ell_at(c.base, cd.N, b + 1);
-                P.ell_idx[eb1] = ia; P.ell_w[eb1] = wa;
-            }
-            // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
-            const int mn = P.ell_idx[ell_at(c.base, cd.N, 0)];
-            for (int a = 1; a < hz; a++) atomicMin(&efirst[P.ell_idx[ell_at(c.base, cd.N, a)]], mn);
         }
         P.ell_meta[cd.crop_off + pos] = (uint32_t)c.nnz | ((uint32_t)hz << 16);
         zmax = c.nnz > zmax ? c.nnz : zmax;
