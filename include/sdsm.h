@@ -54,7 +54,8 @@ typedef struct {
     int32_t smooth_subsample;          /* dsm/smooth_subsample */
     int32_t init_elliptical;           /* dsm/init == 'elliptical' */
     int32_t max_iters;                 /* Newton iteration cap per solve (100 = cvxopt's maxiters) */
-    int32_t reserved;
+    int32_t flags;                     /* bit 0: no "single positive pixel" shortcut (objects.py:184-191) -- for callers that mirror a direct
+                                          cvxprog call, e.g. the normalised energies of c2freganal.py:58-79 */
 } sdsm_dsm_config;
 
 /* One candidate's result (objects.py:198-211).  128 bytes, written by the device. */
@@ -71,7 +72,9 @@ typedef struct {
     int32_t evals_full;     /* pixel passes that computed psi, gradient and Hessian */
     int32_t on_boundary;    /* S > 0 anywhere on the 1-px pad ring (objects.py:209) */
     int32_t fg_r0, fg_c0, fg_h, fg_w;   /* bounding box of the foreground fragment; fg_h == 0: empty */
-    int32_t reserved[3];
+    int32_t n_positive;     /* region pixels with y > 0 */
+    int32_t n_negative;     /* region pixels with y < 0 (C2F: a region whose pixels are all positive or all negative has no energy, c2freganal.py:67-68) */
+    int32_t reserved;
 } sdsm_record;
 
 typedef enum {

@@ -22,14 +22,14 @@ class DsmConfig(C.Structure):
     """sdsm_dsm_config: DSM_CONFIG_DEFAULTS of the reference (superdsm/dsmcfg.py:6-21)."""
     _fields_ = [('scale', C.c_double), ('epsilon', C.c_double), ('alpha', C.c_double), ('smooth_amount', C.c_double),
                 ('gaussian_shape_multiplier', C.c_double), ('background_margin', C.c_double),
-                ('smooth_subsample', C.c_int32), ('init_elliptical', C.c_int32), ('max_iters', C.c_int32), ('reserved', C.c_int32)]
+                ('smooth_subsample', C.c_int32), ('init_elliptical', C.c_int32), ('max_iters', C.c_int32), ('flags', C.c_int32)]
 
 
 RECORD_DTYPE = np.dtype([
     ('energy', 'f8'), ('theta', 'f8', 6), ('energy_ell', 'f8'),
     ('status', 'i4'), ('flags', 'i4'), ('n_pixels', 'i4'), ('n_deform', 'i4'),
     ('iters_ell', 'i4'), ('iters_dsm', 'i4'), ('evals_value', 'i4'), ('evals_full', 'i4'),
-    ('on_boundary', 'i4'), ('fg_r0', 'i4'), ('fg_c0', 'i4'), ('fg_h', 'i4'), ('fg_w', 'i4'), ('reserved', 'i4', 3)])
+    ('on_boundary', 'i4'), ('fg_r0', 'i4'), ('fg_c0', 'i4'), ('fg_h', 'i4'), ('fg_w', 'i4'), ('n_positive', 'i4'), ('n_negative', 'i4'), ('reserved', 'i4')])
 assert RECORD_DTYPE.itemsize == 128
 
 # every entry point of include/sdsm.h: name -> (restype, argtypes)
@@ -101,4 +101,4 @@ def make_config(dsm_cfg):
     return DsmConfig(scale=float(d.get('scale', 1000)), epsilon=float(d.get('epsilon', 1.0)), alpha=float(d.get('alpha', 0.5)),
                      smooth_amount=float(sa), gaussian_shape_multiplier=float(d.get('gaussian_shape_multiplier', 2)),
                      background_margin=float(d.get('background_margin', 20)), smooth_subsample=int(d.get('smooth_subsample', 20)),
-                     init_elliptical=int(d.get('init', 'elliptical') == 'elliptical'), max_iters=int(d.get('max_iters', 100)), reserved=0)
+                     init_elliptical=int(d.get('init', 'elliptical') == 'elliptical'), max_iters=int(d.get('max_iters', 100)), flags=1 if d.get('no_trivial_rule') else 0)

@@ -1,0 +1,82 @@
+"""Normalised set energies r(omega) = nu(omega) / |omega| for the coarse-to-fine region analysis, on the GPU.
+
+Counterpart of ``superdsm.c2freganal._get_cached_normalized_energy_computer`` (c2freganal.py:58-79): the C2F stage splits
+a cluster by watershed and asks, for every part, for the energy of the best ELLIPTICAL model (``dsm/smooth_amount = inf``,
+c2freganal.py:126) of the part's convex-programming region, divided by the region's size.  The watershed / seed logic of
+that stage stays on the host; this module is the operator it calls.
+
+Semantics kept from the reference:
+* the region of a part is ``obj.get_cvxprog_region(masked_cluster, atoms_map, background_margin)`` evaluated on the
+  CLUSTER CROP (objects.py:126-127 run on the cropped image, so the distance transform sees the crop only);
+* a region whose intensities are all positive or all negative has no energy: ``None`` (c2freganal.py:67-68);
+* no "single positive pixel" shortcut: ``cvxprog`` is called directly (c2freganal.py:72);
+* results are cached per region (c2freganal.py:60, 65-66, 76);
+* the value is psi at the optimum of the elliptical model, which does not depend on the coordinate frame (the reference
+  solves in full-image coordinates, c2freganal.py:70-73; here the crop's).
+"""
+import hashlib
+
+import numpy as np
+
+from . import _capi, engine
+from .objects import CvxprogError
+
+
+def normalized_energies(y_crop, mask_crop, atoms_map, footprints, dsm_cfg):
+    """One GPU batch: normalised energy (float) or None per footprint.
+
+    y_crop / mask_crop: offset intensities and admissible pixels of the cluster crop; atoms_map: integer labels of the
+    crop; footprints: iterable of label sets; dsm_cfg: DSM hyper-parameters (``smooth_amount`` is forced to inf)."""
+    footprints = [sorted(int(a) for a in fp) for fp in footprints]
+    if not footprints:
+        return []
+    cfg = {k: v for k, v in dsm_cfg.items() if k not in ('smooth_mat_max_allocations', 'smooth_mat_dtype', 'cachesize', 'cachetest', 'cp_timeout')}
+    cfg['smooth_amount'] = np.inf
+    cfg['no_trivial_rule'] = True
+    margin = cfg.pop('background_margin')
+    img = engine.DeviceImage(np.ascontiguousarray(y_crop, np.float64), None if mask_crop is None else np.ascontiguousarray(mask_crop, bool),
+                             np.ascontiguousarray(atoms_map, np.int32), margin)
+    batch = engine.Batch(img, footprints, cfg, latency_mode=True)
+    batch.launch()
+    recs = batch.records()
+    out = []
+    for i, r in enumerate(recs[:len(footprints)]):
+        n = int(r['n_pixels'])
+        if n == 0 or r['n_positive'] == n or r['n_negative'] == n:        # c2freganal.py:67-68 (.all() of nothing is True)
+            out.append(None)
+        elif r['status'] in (_capi.CAND_ERROR, _capi.CAND_UNSUPPORTED):
+            raise CvxprogError(cidx=i)
+        else:
+            out.append(float(r['energy']) / n)
+    return out
+
+
+class NormalizedEnergyComputer:
+    """``compute_normalized_energy(obj, region, atoms_map, dsm_cfg)`` with the reference's signature and cache."""
+
+    def __init__(self, y, cluster):
+        self.y, self.cluster = y, cluster
+        self.cache = {}
+
+    @staticmethod
+    def _key(obj, region, atoms_map):
+        m = np.logical_and(region.mask, np.isin(atoms_map, list(obj.footprint)))
+        return hashlib.sha1(np.ascontiguousarray(m, np.uint8)).digest()
+
+    def compute_many(self, objs, region, atoms_map, dsm_cfg):
+        """Energies of several parts of the same cluster in ONE batch (a split yields two)."""
+        keys = [self._key(o, region, atoms_map) for o in objs]
+        todo = [i for i, k in enumerate(keys) if k not in self.cache]
+        if todo:
+            vals = normalized_energies(region.model, region.mask, atoms_map, [objs[i].footprint for i in todo], dsm_cfg)
+            for i, v in zip(todo, vals):
+                self.cache[keys[i]] = v
+        return [self.cache[k] for k in keys]
+
+    def __call__(self, obj, region, atoms_map, dsm_cfg):
+        return self.compute_many([obj], region, atoms_map, dsm_cfg)[0]
+
+
+def get_cached_normalized_energy_computer(y, cluster):
+    """Drop-in for ``c2freganal._get_cached_normalized_energy_computer``."""
+    return NormalizedEnergyComputer(y, cluster)

@@ -330,7 +330,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     hipStream_t s = (hipStream_t)stream;
     BatchParams P{};
     P.n = p->n; P.H = p->H; P.W = p->W; P.n_atoms = p->n_atoms;
-    P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.no_deform = p->no_deform;
+    P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
     P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels;
     P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
     P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);

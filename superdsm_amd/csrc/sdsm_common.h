@@ -72,15 +72,18 @@ struct CandState {
     unsigned long long sum_r, sum_c, sum_rr, sum_cc;   // moments of the y > 0 pixels (image coordinates)
     int32_t hzmax;      // largest number of 'significant' entries (>= hess_thr * row maximum) in a row of G~
     int32_t env_size;   // doubles of the solver's Hessian in envelope storage (see env_fst / env_rb)
+    int32_t nneg;       // region pixels with y < 0
+    int32_t pad1;
     int32_t gcount[8];  // gcount[j] = crop positions whose row has more than 4 j entries (positions are sorted by that)
 };
-static_assert(sizeof(CandState) == 96 && SDSM_ELL_GROUPS_REG <= 8, "CandState layout");
+static_assert(sizeof(CandState) == 104 && SDSM_ELL_GROUPS_REG <= 8, "CandState layout");
 static_assert(sizeof(CandDesc) == 80, "CandDesc layout");
 
 struct BatchParams {
     int32_t n, H, W, n_atoms;
     int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, ELL slots per pixel (a multiple of 4)
     int32_t no_deform;                 // smooth_amount == inf
+    int32_t no_trivial_rule;           // sdsm_dsm_config.flags bit 0: solve even a region with a single positive pixel (cvxprog called directly, c2freganal.py:58-79)
     int32_t init_elliptical, max_iters;
     int32_t k1_pixmax;                 // regions with more pixels are solved by class 2 (INT_MAX: throughput mode)
     double scale, epsilon, alpha;

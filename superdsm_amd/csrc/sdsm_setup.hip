@@ -106,7 +106,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     __shared__ unsigned long long mom[4];
     __shared__ unsigned long long scr64[SDSM_WAVES];
     __shared__ int scr32[SDSM_WAVES];
-    __shared__ int sh_M, sh_npos, sh_err;
+    __shared__ int sh_M, sh_npos, sh_nneg, sh_err;
     __shared__ int cls_cnt[SDSM_MAX_ELL_GROUPS + 1], cls_start[SDSM_MAX_ELL_GROUPS + 1], cls_run[SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int wave_cnt[SDSM_WAVES][SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int efirst[SDSM_MAX_N_SOLVE];             // envelope of the solver's Hessian: first coupled column per grid point
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     for (int i = tid; i < (SDSM_MAX_LABELS + 1) / 32; i += SDSM_WG) fpbits[i] = 0;
     for (int i = tid; i < SDSM_MAX_BBOX_DIM / 32; i += SDSM_WG) { rowbits[i] = 0; colbits[i] = 0; }
     if (tid < 4) mom[tid] = 0;
-    if (tid == 0) { sh_M = 0; sh_npos = 0; sh_err = 0; }
+    if (tid == 0) { sh_M = 0; sh_npos = 0; sh_nneg = 0; sh_err = 0; }
     __syncthreads();
     for (int i = tid; i < cd.fp_len; i += SDSM_WG) {
         int l = P.fp_labels[cd.fp_off + i];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     const int area = cd.h * cd.w;
     int running = 0;
     unsigned long long m_r = 0, m_c = 0, m_rr = 0, m_cc = 0;
-    int npos = 0;
+    int npos = 0, nneg = 0;
     for (int base = 0; base < area; base += SDSM_WG) {
         int i = base + tid;
         bool flag = false;
@@ -161,6 +161,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             }
             atomicOr(&rowbits[r >> 5], 1u << (r & 31));
             atomicOr(&colbits[c >> 5], 1u << (c & 31));
+            if (yv < 0) nneg++;
             if (yv > 0) {
                 unsigned long long rr = cd.r0 + r, cc = cd.c0 + c;
                 npos++; m_r += rr; m_c += cc; m_rr += rr * rr; m_cc += cc * cc;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         }
         running += total;
     }
+    if (nneg) atomicAdd(&sh_nneg, nneg);
     if (npos) { atomicAdd(&sh_npos, npos); atomicAdd(&mom[0], m_r); atomicAdd(&mom[1], m_c); atomicAdd(&mom[2], m_rr); atomicAdd(&mom[3], m_cc); }
     __syncthreads();
 
@@ -190,10 +192,10 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     __syncthreads();
 
     CandState s = {};
-    s.hc = hc; s.wc = wc; s.npos = sh_npos;
+    s.hc = hc; s.wc = wc; s.npos = sh_npos; s.nneg = sh_nneg;
     s.sum_r = mom[0]; s.sum_c = mom[1]; s.sum_rr = mom[2]; s.sum_cc = mom[3];
     if (running != cd.N) { s.status = ST_ERROR; if (tid == 0) *st = s; return; }          // plan / image mismatch
-    if (s.npos == 1) { s.status = ST_TRIVIAL; if (tid == 0) *st = s; return; }            // objects.py:184-191 (no solve)
+    if (s.npos == 1 && !P.no_trivial_rule) { s.status = ST_TRIVIAL; if (tid == 0) *st = s; return; }            // objects.py:184-191 (no solve)
 
     const int S = P.subsample, R = P.R;
     const bool null_matrix = P.no_deform || hc <= P.k / 2 || wc <= P.k / 2;               // dsm.py:187,225

@@ -1145,6 +1145,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         r.energy = status_final == SDSM_CAND_ERROR ? NAN : psi_final;
         r.status = status_final;
         r.evals_value = ev_value; r.evals_full = ev_full;
+        r.n_positive = st.npos; r.n_negative = st.nneg;
         r.on_boundary = onb;
 #ifdef SDSM_PROFILE
         prof_acc[5] = PROF_NOW() - prof_t_start;

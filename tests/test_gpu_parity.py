@@ -480,3 +480,58 @@ def test_wide_envelope_and_long_rows_use_the_global_memory_class(gpu):
     frag = batch.fragments(batch.records())[0]
     from superdsm_amd import testing
     assert testing.dice(frag[0], frag[1], orecs['fg_offset'][0], ofrags[0], (H, W)) >= 0.999
+
+
+def test_c2f_normalized_energies_match_oracle(gpu, monkeypatch):
+    """the operator the C2F stage calls (c2freganal.py:58-79) -- elliptical models only, region on the
+    cluster crop, None for one-signed regions, no single-positive-pixel shortcut, cache per region."""
+    import scipy.ndimage as ndi
+    from oracle import oracle
+    from superdsm_amd import c2f_energy, engine, image, objects
+    rng = np.random.default_rng(21)
+    H, W = 70, 96
+    rr, cc = np.mgrid[:H, :W]
+    y = -0.12 + 0.02 * rng.standard_normal((H, W))
+    y = np.minimum(y, -0.005)
+    y[((rr - 34) / 20.0) ** 2 + ((cc - 30) / 17.0) ** 2 <= 1] = 0.3          # two touching nuclei: one cluster
+    y[((rr - 36) / 16.0) ** 2 + ((cc - 62) / 19.0) ** 2 <= 1] = 0.25
+    atoms_map = np.ones((H, W), np.int64)
+    atoms_map[:, 46:] = 2                                                    # the split
+    atoms_map[30:40, 25:33] = 3                                              # a part inside a nucleus: all positive -> None
+    atoms_map[:6, :6] = 4                                                    # background corner ...
+    y[2, 2] = 0.2                                                            # ... with a single positive pixel
+    y_mask = np.ones((H, W), bool)
+    y_mask[:, 90:] = False
+    cfg = dict(scale=1000, epsilon=1.0, alpha=0.033, smooth_amount=4, smooth_subsample=8, gaussian_shape_multiplier=2,
+               background_margin=7, init='elliptical', cachesize=1, cp_timeout=300, smooth_mat_max_allocations=np.inf)
+    yi = image.Image.create_from_array(y, normalize=False)
+    cluster = yi.get_region(np.ones((H, W), bool), shrink=True)
+    masked = cluster.get_region(cluster.shrink_mask(y_mask))
+    fps = [{1}, {2}, {1, 2}, {3}, {4}, {1, 3}]
+    objs = []
+    for fp in fps:
+        o = objects.Object()
+        o.footprint = frozenset(fp)
+        objs.append(o)
+    comp = c2f_energy.get_cached_normalized_energy_computer(yi, cluster)
+    got = comp.compute_many(objs, masked, atoms_map, cfg)
+    # host restatement with the oracle's cvxprog on the same regions
+    near = ndi.distance_transform_edt(y <= 0) <= cfg['background_margin']
+    cfg_inf = {k: v for k, v in cfg.items() if k in ('scale', 'epsilon', 'alpha', 'smooth_subsample', 'gaussian_shape_multiplier', 'init')}
+    cfg_inf['smooth_amount'] = np.inf
+    for fp, g in zip(fps, got):
+        m = np.isin(atoms_map, list(fp)) & y_mask & near
+        vals = y[m]
+        if (vals > 0).all() or (vals < 0).all():
+            assert g is None, fp
+            continue
+        _, info = oracle.cvxprog(y, m, cfg_inf)
+        want = info['energy'] / m.sum()
+        assert g is not None and abs(g - want) <= 1e-5 * abs(want) + 1e-9, (fp, g, want)
+    assert got[3] is None and got[4] is not None          # the all-positive part; the single positive pixel is solved, not skipped
+    # cache: asking again launches nothing
+    calls = []
+    real = engine.Batch
+    monkeypatch.setattr(engine, 'Batch', lambda *a, **k: calls.append(1) or real(*a, **k))
+    again = [comp(o, masked, atoms_map, cfg) for o in objs]
+    assert calls == [] and again == got
