@@ -40,6 +40,7 @@ class Object(BaseObject):
         self.on_boundary = np.nan
         self.is_optimal = np.nan
         self.processing_time = np.nan
+        self.cvxprog_region_size = 0      # extension: pixels of the convex-programming region (compute_norm_energy)
 
     def get_mask(self, atoms):
         return np.isin(atoms, list(self.footprint))
@@ -50,6 +51,7 @@ class Object(BaseObject):
         self.footprint = set(state.footprint)
         for attr in ('energy', 'on_boundary', 'is_optimal', 'processing_time'):
             setattr(self, attr, getattr(state, attr))
+        self.cvxprog_region_size = getattr(state, 'cvxprog_region_size', 0)
         return self
 
     def copy(self):
@@ -99,6 +101,11 @@ def _device_image(y, atoms, background_margin):
     return cache[1]
 
 
+def compute_norm_energy(obj):
+    """``postprocess._compute_norm_energy`` (postprocess.py:289-291) without recomputing the region: compute_objects keeps its size."""
+    return obj.energy / obj.cvxprog_region_size
+
+
 def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, shard=None):
     """Computes ``energy``, ``on_boundary``, ``is_optimal``, ``processing_time``, ``fg_offset`` and ``fg_fragment`` of
     every object IN PLACE (objects.py:243-267).
@@ -146,6 +153,9 @@ def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAUL
         obj.energy = float(rec['energy'])
         obj.on_boundary = bool(rec['on_boundary'])
         obj.is_optimal = status == _capi.CAND_OPTIMAL
+        # size of the convex-programming region: what postprocess._compute_norm_energy divides by (postprocess.py:289-291; the
+        # reference recomputes the region with a full-image distance transform per object)
+        obj.cvxprog_region_size = int(rec['n_pixels'])
         # the batch is solved concurrently: the wall time is attributed evenly (the reference records the per-task time)
         obj.processing_time = 0 if status == _capi.CAND_TRIVIAL else dt / len(objects)
         fallbacks += status == _capi.CAND_FALLBACK

@@ -390,6 +390,7 @@ def test_edge_cases_trivial_masked_border_and_elliptical_only(gpu):
     objects.compute_objects([], yi, atoms, cfg, None, out='muted')
     objects.compute_objects(objs, yi, atoms, dict(cfg, cachesize=1, cp_timeout=300, smooth_mat_max_allocations=np.inf), None, out='muted')
     assert objs[1].energy == 0 and objs[1].is_optimal is False and objs[0].is_optimal is True
+    assert objs[0].copy().cvxprog_region_size == orecs['N'][0] and abs(objects.compute_norm_energy(objs[0]) - orecs['energy'][0] / orecs['N'][0]) <= 1e-8   # postprocess.py:289-291
     assert abs(objs[0].energy - orecs['energy'][0]) <= 1e-5 * abs(orecs['energy'][0]) + 1e-6
     # elliptical models only (smooth_amount = inf): what the reference's C2F stage asks of the operator (c2freganal.py:126)
     cfg_inf = dict(cfg, smooth_amount=np.inf)
