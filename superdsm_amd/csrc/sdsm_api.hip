@@ -346,7 +346,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.psf = (const float *)(b + p->off_psf);
     P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
     P.hglob = (double *)(b + p->off_hglob);
-    P.prof = g_prof;
+    P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     if ((e = sdsm_launch_setup(P, d_y, d_atoms, d_valid, s)) != hipSuccess) return hipfail(e, "launch setup");

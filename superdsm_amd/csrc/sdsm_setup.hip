@@ -15,7 +15,8 @@ namespace {
 
 struct WeightCtx {
     int cr, cc, R, k;
-    const float *psf;
+    const float *psf;       // global table
+    const float *psf_lds;   // the same in LDS, or nullptr
     const uint32_t *keys;   // sorted grid keys in LDS
     int jlo, jhi;           // grid points whose (compressed) row lies within R of the pixel's: the only ones that can be in the window
     int nnz;                // entries of the row (grid points inside the PSF window)
@@ -31,7 +32,8 @@ __device__ __forceinline__ float wval(WeightCtx &c, int j)
     int dr = (int)(key >> 16) - c.cr, dc = (int)(key & 0xffffu) - c.cc;
     int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
     if (adr <= c.R && adc <= c.R) {
-        float v = c.psf[(c.R + dr) * c.k + (c.R + dc)];
+        const int pidx = (c.R + dr) * c.k + (c.R + dc);
+        float v = c.psf_lds ? c.psf_lds[pidx] : c.psf[pidx];
         c.wmax = v > c.wmax ? v : c.wmax;
         c.nnz++;
         return v;
@@ -99,7 +101,9 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
                                                          const int32_t *__restrict__ atoms,
                                                          const uint8_t *__restrict__ valid)
 {
-    __shared__ uint32_t fpbits[(SDSM_MAX_LABELS + 1) / 32];
+    // footprint bitset during the region scan (2048 words), then the PSF table (k * k floats, if it fits) for the rows of G~
+    __shared__ uint32_t fp_or_psf[SDSM_PSF_LDS];
+    uint32_t *fpbits = fp_or_psf;
     __shared__ uint32_t rowbits[SDSM_MAX_BBOX_DIM / 32], colbits[SDSM_MAX_BBOX_DIM / 32];
     __shared__ uint16_t rowrank[SDSM_MAX_BBOX_DIM], colrank[SDSM_MAX_BBOX_DIM];
     __shared__ uint32_t gridkeys[SDSM_MAX_GRID];
@@ -111,6 +115,12 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     __shared__ int wave_cnt[SDSM_WAVES][SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int efirst[SDSM_MAX_N_SOLVE];             // envelope of the solver's Hessian: first coupled column per grid point
 
+#ifdef SDSM_PROFILE
+    long long sp_t = PROF_NOW(), sp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SETUP_T(k) do { long long _n = PROF_NOW(); sp_acc[k] += _n - sp_t; sp_t = _n; } while (0)
+#else
+#define SETUP_T(k) do { } while (0)
+#endif
     const int tid = threadIdx.x;
     const int ci = P.order[blockIdx.x];
     const CandDesc cd = P.cand[ci];
@@ -173,6 +183,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     if (npos) { atomicAdd(&sh_npos, npos); atomicAdd(&mom[0], m_r); atomicAdd(&mom[1], m_c); atomicAdd(&mom[2], m_rr); atomicAdd(&mom[3], m_cc); }
     __syncthreads();
 
+    SETUP_T(0);
     // ---- 2. compressed coordinates: delete empty rows / columns (dsm.py:185-186) ---------------
     for (int r = tid; r < cd.h; r += SDSM_WG) {
         int cnt = 0;
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     int M = sh_M;
     if (M > cap) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
 
+    SETUP_T(1);
     // ---- 3. greedy completion of the grid (dsm.py:169-181) --------------------------------------
     for (int i = tid; i < cd.N; i += SDSM_WG) {
         uint32_t key = P.crop_cc[cd.crop_off + i];
@@ -267,6 +279,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         return;
     }
 
+    SETUP_T(2);
     // ---- 4. columns of G~ = grid points in raster order (np.nonzero(col_mask), dsm.py:159) ------
     for (int j = tid; j < M; j += SDSM_WG) {
         uint32_t key = gridkeys[j];
@@ -287,6 +300,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     }
     __syncthreads();
 
+    SETUP_T(3);
     // ---- 4b. final crop order: stable counting sort of the scan order by the number of 4-entry groups of the pixel's
     //      G~ row, largest first.  A wavefront of the solve kernel then reads 64 rows of (nearly) the same length and
     //      fetches only the groups that exist (CandState.gcount), instead of every row padded to the longest one. ------
@@ -354,7 +368,15 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     for (int j = tid; j < M; j += SDSM_WG) efirst[j] = j;
     __syncthreads();
 
+    SETUP_T(4);
     // ---- 5. rows of G~: PSF gather, float32 pairwise row sum, float32 division (dsm.py:192-193) --
+    const float *psf_lds = nullptr;
+    if (P.k * P.k <= SDSM_PSF_LDS) {                     // the footprint bitset is no longer needed
+        float *pl = reinterpret_cast<float *>(fp_or_psf);
+        for (int e = tid; e < P.k * P.k; e += SDSM_WG) pl[e] = P.psf[e];
+        psf_lds = pl;
+        __syncthreads();
+    }
     bool bad = false;
     int zmax = 0, hzmax = 0;
     for (int pos = tid; pos < cd.N; pos += SDSM_WG) {     // in final crop order: neighbouring lanes write neighbouring rows
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         uint32_t key = P.crop_cc[cd.crop_off + i];
         // pass 1 over the grid points: row sum in numpy's order, largest entry, number of entries (nothing is stored)
         WeightCtx c;
-        c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.keys = gridkeys; c.nnz = 0; c.wmax = 0.f;
+        c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.psf_lds = psf_lds; c.keys = gridkeys; c.nnz = 0; c.wmax = 0.f;
         c.jlo = growstart[c.cr - R > 0 ? c.cr - R : 0]; c.jhi = c.cr + R + 1 < hc ? growstart[c.cr + R + 1] : M;
         const int64_t base = cd.ell_off + (int64_t)pos * 4;
         P.crop_y[cd.crop_off + pos] = P.tmp_y[cd.crop_off + i];
@@ -379,7 +401,8 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             int dr = (int)(gk >> 16) - c.cr, dc = (int)(gk & 0xffffu) - c.cc;
             const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
             if (adr > R || adc > R) continue;
-            const float nw = __fdiv_rn(P.psf[(R + dr) * P.k + (R + dc)], sum);
+            const int pidx = (R + dr) * P.k + (R + dc);
+            const float nw = __fdiv_rn(psf_lds ? psf_lds[pidx] : P.psf[pidx], sum);
             int slot;
             if (!(nw < lim)) {
                 slot = hz++;
@@ -405,6 +428,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     zmax = -block_min_i32(-zmax, scr32);
     hzmax = -block_min_i32(-hzmax, scr32);
     __syncthreads();
+    SETUP_T(5);
     // ---- 6. envelope storage of the Hessian (BatchParams.env_fst / env_rb): first columns made non-decreasing and
     //      multiples of SDSM_PANEL (the factorisation works on panels of that many columns), row bases by a running sum ------------
     if (tid == 0) {
@@ -426,6 +450,10 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     }
     s.status = sh_err ? ST_ERROR : ST_OK;
     if (tid == 0) *st = s;
+    SETUP_T(6);
+#ifdef SDSM_PROFILE
+    if (P.prof2 && tid == 0) for (int k = 0; k < 8; k++) P.prof2[(size_t)ci * 8 + k] = sp_acc[k];
+#endif
 }
 
 extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream)

@@ -16,13 +16,15 @@ scene = testing.make_scene(wl, max_size=3)
 fps = scene['footprints']
 img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
 batch = engine.Batch(img, fps, scene['dsm_cfg'])
-prof = torch.zeros(len(fps) * 16, dtype=torch.int64, device='cuda')
+prof = torch.zeros(len(fps) * 24, dtype=torch.int64, device='cuda')     # 16 solve + 8 setup counters per candidate
 _capi.lib().sdsm_set_debug_buffer(C.c_void_p(prof.data_ptr()))
 for _ in range(2):
     batch.launch()
 torch.cuda.synchronize()
 recs = batch.records()
-p = prof.cpu().numpy().reshape(-1, 16).astype(np.float64)
+pall = prof.cpu().numpy()
+p = pall[:len(fps) * 16].reshape(-1, 16).astype(np.float64)
+ps = pall[len(fps) * 16:].reshape(-1, 8).astype(np.float64)
 names = ['phaseA', 'phaseB', 'reduce', 'factor', 'linesrch', 'total', 'ell_tot']
 n = recs['n_deform'] + 6
 cls = np.where(n <= 40, 'A', np.where(n <= 84, 'B', np.where(n <= 172, 'C', 'D')))  # size bands for reporting only
@@ -48,6 +50,9 @@ if p[:, 8:12].sum() > 0 and p[:, 13:16].sum() > 0:
     m = cls == 'B'
     tot = p[m, 8:12].sum()
     print('panel loop of the factorisation, class B, thread 0: diagonal block %.1f%%  trailing update %.1f%%  barrier wait %.1f%%  write-back %.1f%%' % tuple(100 * p[m, 8 + i].sum() / tot for i in range(4)))
+if ps.sum() > 0:
+    names_s = ['region scan', 'compressed coords + lattice', 'greedy grid', 'grid sort + row table', 'row lengths + counting sort', 'rows of G~ (2 passes)', 'envelope + state']
+    print('setup kernel, thread 0, share of its time: ' + ',  '.join('%s %.1f%%' % (nm, 100 * ps[:, k].sum() / ps.sum()) for k, nm in enumerate(names_s)) + '   (median total %.0f us)' % (np.median(ps.sum(1)) / 2400))
 print('slowest candidates:')
 for k in worst:
     print('  cand %d N=%d M=%d it_ell=%d it_dsm=%d evals=%d/%d total=%.2f ms  A=%.2f B=%.2f red=%.2f fac=%.2f ls=%.2f' % (
