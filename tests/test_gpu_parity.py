@@ -536,3 +536,53 @@ def test_c2f_normalized_energies_match_oracle(gpu, monkeypatch):
     monkeypatch.setattr(engine, 'Batch', lambda *a, **k: calls.append(1) or real(*a, **k))
     again = [comp(o, masked, atoms_map, cfg) for o in objs]
     assert calls == [] and again == got
+
+
+@pytest.mark.parametrize('seed,sigma,subsample', [(1, 4, 8), (2, 2, 4), (3, 6, 12), (4, 4, 5), (5, 3, 6)])
+def test_random_shapes_and_hyperparameters_match_oracle(gpu, seed, sigma, subsample):
+    """Irregular regions (concave, with holes, thin bridges, cut by the image border and by y_mask) under several
+    (smooth_amount, smooth_subsample) pairs: grids that are not lattices, non-monotone Hessian envelopes, rows of G~ of
+    very different lengths.  Energies against the oracle, masks by Dice."""
+    from oracle import oracle
+    from superdsm_amd import engine, testing
+    rng = np.random.default_rng(100 + seed)
+    H, W = 90, 110
+    rr, cc = np.mgrid[:H, :W]
+    y = -0.15 + 0.03 * rng.standard_normal((H, W))
+    for _ in range(7):                                                        # overlapping blobs of random shape
+        r0, c0 = rng.uniform(5, H - 5), rng.uniform(5, W - 5)
+        a, b, th = rng.uniform(6, 22), rng.uniform(6, 22), rng.uniform(0, np.pi)
+        u = (rr - r0) * np.cos(th) + (cc - c0) * np.sin(th)
+        v = -(rr - r0) * np.sin(th) + (cc - c0) * np.cos(th)
+        y += rng.uniform(0.25, 0.5) * np.exp(-1.3 * ((u / a) ** 2 + (v / b) ** 2) ** 1.5)
+    y_mask = np.ones((H, W), bool)
+    for _ in range(3):                                                        # holes in the admissible area
+        r0, c0 = rng.integers(10, H - 10), rng.integers(10, W - 10)
+        y_mask[r0:r0 + rng.integers(2, 7), c0:c0 + rng.integers(2, 9)] = False
+    # atoms: a random Voronoi partition (irregular, concave unions)
+    seeds = np.stack([rng.uniform(0, H, 9), rng.uniform(0, W, 9)], 1)
+    atoms = 1 + np.argmin((rr[..., None] - seeds[:, 0]) ** 2 + (cc[..., None] - seeds[:, 1]) ** 2, axis=2).astype(np.int32)
+    fps = [[a] for a in range(1, 10)] + [[1, 2], [3, 4, 5], [2, 6, 7, 8], [1, 3, 5, 7, 9], list(range(1, 10))]
+    cfg = dict(scale=1000, epsilon=1.0, alpha=0.04, smooth_amount=sigma, smooth_subsample=subsample, gaussian_shape_multiplier=2,
+               background_margin=6, init='elliptical')
+    img = engine.DeviceImage(y, y_mask, atoms, cfg['background_margin'])
+    batch = engine.Batch(img, fps, cfg)
+    batch.launch()
+    gpu.cuda.synchronize()
+    recs = batch.records()
+    frags = batch.fragments(recs)
+    orecs, ofrags, _ = oracle.compute_objects(y, y_mask, atoms, fps, cfg, nthreads=0)
+    checked = 0
+    for k in range(len(fps)):
+        if orecs['status'][k] == 2:                                           # trivial (single positive pixel)
+            assert recs['status'][k] == 2
+            continue
+        assert (recs['n_pixels'][k], recs['n_deform'][k]) == (orecs['N'][k], orecs['M'][k]), k
+        if orecs['status'][k] != 0 or recs['status'][k] != 0:
+            assert recs['energy'][k] <= orecs['energy'][k] * (1 + 1e-6) + 1e-9, k   # a fallback on either side: not worse than the oracle's value
+            continue
+        tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
+        assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (k, recs['energy'][k], orecs['energy'][k])
+        assert testing.dice(frags[k][0], frags[k][1], orecs['fg_offset'][k], ofrags[k], (H, W)) >= 0.995, k
+        checked += 1
+    assert checked >= 8
