@@ -116,13 +116,13 @@ struct sdsm_plan {
     sdsm_dsm_config cfg{};
     int k = 1, R = 0, zcap = 1, no_deform = 0;
     std::vector<CandDesc> cand;
-    std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those that may reach class C, then class D
+    std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those whose bound on M admits more than solve class 1, then more than class 2
     int n_order_c = 0, n_order_d = 0;
     int wide_pixels = INT_MAX;   // throughput mode by default
     std::vector<float> psf;
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
-    int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hsave = 0, n_hglob = 0;
+    int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0;
     size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_ell_meta = 0,
            off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, total = 0;
 };

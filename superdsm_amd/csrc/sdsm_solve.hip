@@ -1,5 +1,5 @@
 // Per-candidate convex solve: elliptical model, deformable shape model, final energy, mask, record.
-// One persistent 256-thread workgroup per candidate; all solver state lives in LDS.
+// One persistent workgroup per candidate (256 or 512 threads by size class); all solver state lives in LDS.
 //
 // Reference behaviour restated here (never its code):
 //   surface S, energy psi, gradient, Hessian   superdsm/dsm.py:86-94, 291-385   
@@ -8,19 +8,19 @@
 //   mask tail                                   superdsm/objects.py:198-209, dsm.py:113-128 (A9)
 // The reference hands scale*psi to cvxopt.solvers.cp (dsm.py:488); cvxopt is a third-party dependency
 // that is not part of the reference tree.  The solver here is the damped Newton iteration specified in
-// DESIGN.md ("Solver"), identical step for step to the oracle's orc_newton, but run in a centred and
-// scaled local polynomial basis (psi is invariant under affine re-parametrisation of theta).
+// DESIGN.md ("Solver"), the same algorithm and constants as the oracle's orc_newton (different elimination order and
+// summation order, so iterates agree to rounding), run in a centred and scaled local polynomial basis (psi is
+// invariant under affine re-parametrisation of theta).
 //
 // One full evaluation (psi, gradient, Hessian) of a candidate with n = 6 + M parameters:
 //   every lane owns pixels: coalesced read of the packed crop (y f64 + (row,col) u16x2 = 12 B / pixel) and of the
-//   pixel's ELL row of G~ (slot-major, fixed trip count, all loads of a row issued before the first use), S,
-//   exp/log, residual r and curvature weight d.  psi, the 6 polynomial gradient entries and the 6x6 polynomial
-//   Hessian block are per-lane register sums reduced with wavefront shuffles + one LDS hop.  The xi part of the
-//   gradient (every entry of the row) and of the Hessian (the row's leading "significant" entries, weight >= 5 % of
-//   the row maximum: the solver's approximate Hessian) is added straight into LDS with ds_add_f64; the crop is
-//   stored scattered (CandDesc.perm_inv) so that the 64 lanes of a wave touch different (j,k) entries.
-//   (A register-tiled dense J^T diag(d) J over LDS-staged Jacobian rows was measured 10 % slower even at 6+M <= 40
-//   once the Hessian was thresholded, and was removed.)
+//   pixel's row of G~ (4 entries per load, only the groups its 64-position chunk has, all loads issued before the first
+//   use), S, the logistic loss without libm, residual r and curvature weight d.  psi, the 6 polynomial gradient entries
+//   and the 6x6 polynomial Hessian block are per-lane register sums reduced with a reduce-scatter butterfly + one LDS
+//   hop.  The xi part of the gradient (every entry of the row) and of the Hessian (the row's leading entries, weight
+//   >= 10 % of the row maximum: the solver's approximate Hessian, stored as an envelope) is added straight into LDS with
+//   ds_add_f64; the crop order scatters neighbouring pixels so that the 64 lanes of a wave touch different entries.
+//   One line-search sweep evaluates psi(x + t d) for 8 step lengths in a single pass (S is linear in t).
 #include "sdsm_common.h"
 #include <climits>
 
@@ -578,7 +578,7 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Solve (H + tau D) d = -g, D = diag(H): Jacobi scaling, then a blocked right-looking Cholesky IN PLACE on the envelope
+// Solve (H + tau D) d = -g, D = diag(H): blocked right-looking Cholesky IN PLACE on the envelope
 // (panels of NB = 4 columns, the right-hand side rides along as row n), then blocked back substitution.
 // A panel only touches the rows whose envelope reaches its columns (xi rows up to rend[panel], the 6 theta rows and
 // the right-hand side): about (bandwidth + 7)^2 / 2 entries per panel instead of the whole trailing triangle.
