@@ -163,6 +163,7 @@ def main():
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
                      'kernel': 'sdsm_k_solve (all three size classes of one launch)', 'kernel_ms': kern_ms, 'setup_kernel_ms': setup_ms,
                      'algorithmic_bytes_per_launch': alg_bytes,
+                     'achieved_with_steps_in_flight': alg_bytes * world / (dt / args.steps) / 1e9 / world,   # same bytes over the time per step of the timed region (per GPU)
                      'fp64_vector_tflops': flops / (kern_ms * 1e-3) / 1e12, 'fp64_vector_frac_of_78.6': flops / (kern_ms * 1e-3) / 1e12 / 78.6,
                      'pixel_evaluations_per_launch': int((evals * recs['n_pixels']).sum())},
         'status_counts': {str(k): int(v) for k, v in zip(*np.unique(recs['status'], return_counts=True))},
