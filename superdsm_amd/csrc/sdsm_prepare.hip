@@ -78,17 +78,32 @@ __global__ void k_stats_init(int32_t *stats, int n_atoms)
     s[0] = 0; s[1] = 0x7fffffff; s[2] = -1; s[3] = 0x7fffffff; s[4] = -1; s[5] = 0;
 }
 
+// Per-atom area and extents.  A wavefront covers 64 consecutive columns of one row, which mostly belong to one or two
+// atoms: the lanes of each label present are aggregated with ballots and ONE lane issues the 5 atomics for them.
 __global__ void k_stats(const int32_t *__restrict__ atoms, const uint8_t *__restrict__ valid, int H, int W, int n_atoms, int32_t *stats)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= W) return;
-    size_t p = (size_t)r * W + c;
-    int l = atoms[p];
-    if (l < 1 || l > n_atoms || !valid[p]) return;
-    int32_t *s = stats + (size_t)l * SDSM_ATOM_STATS_STRIDE;
-    atomicAdd(&s[0], 1);
-    atomicMin(&s[1], r); atomicMax(&s[2], r);
-    atomicMin(&s[3], c); atomicMax(&s[4], c);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    int l = 0;
+    if (c < W) {
+        const size_t p = (size_t)r * W + c;
+        l = atoms[p];
+        if (l < 1 || l > n_atoms || !valid[p]) l = 0;
+    }
+    unsigned long long todo = __ballot(l != 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int l0 = __shfl(l, src);
+        const unsigned long long same = __ballot(l == l0);
+        if (lane == src) {
+            int32_t *s = stats + (size_t)l0 * SDSM_ATOM_STATS_STRIDE;
+            const int c0 = c - lane;                                       // column of lane 0
+            atomicAdd(&s[0], __popcll(same));
+            atomicMin(&s[1], r); atomicMax(&s[2], r);
+            atomicMin(&s[3], c0 + __ffsll((long long)same) - 1); atomicMax(&s[4], c0 + 63 - __clzll((long long)same));
+        }
+        todo &= ~same;
+    }
 }
 
 // ---- reductions for np.std (preprocess.py:52) ------------------------------------------------------
