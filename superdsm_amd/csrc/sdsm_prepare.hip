@@ -26,7 +26,7 @@ __global__ void k_target(const double *__restrict__ src, size_t n, int mode, con
         t = src[i] > thr;
         target[i] = t;
     }
-    if (__any(t) && (threadIdx.x & 63) == 0) atomicOr(any, 1);
+    if (__syncthreads_or(t) && threadIdx.x == 0) *any = 1;       // every writer stores the same value: no atomic needed
 }
 
 // horizontal distance to the nearest target in the same row, capped at radius + 1
