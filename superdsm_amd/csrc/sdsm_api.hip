@@ -13,7 +13,7 @@
 #include <climits>
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
-                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev, int n_c, int n_d);
+                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev, int n_c, int n_d, int n_w);
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
@@ -117,14 +117,14 @@ struct sdsm_plan {
     int k = 1, R = 0, zcap = 1, no_deform = 0;
     std::vector<CandDesc> cand;
     std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those whose bound on M admits more than solve class 1, then more than class 2
-    int n_order_c = 0, n_order_d = 0;
+    int n_order_c = 0, n_order_d = 0, n_order_w = 0;   // the last list: (candidate | member << 24) of the workgroup groups
     int wide_pixels = INT_MAX;   // throughput mode by default
     std::vector<float> psf;
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
-    int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0;
+    int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0, n_wide = 0;
     size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_ell_meta = 0,
-           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, total = 0;
+           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, total = 0;
 };
 
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -195,7 +195,10 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
             const int64_t nn = 6 + std::min<int64_t>(c.Mcap, SDSM_MAX_N_SOLVE - 6);
             c.hglob_off = p->n_hglob; p->n_hglob += nn * (nn + 1) / 2;
         } else c.hglob_off = -1;
-        c.pad = 0;
+        if (N > SDSM_WIDE_MIN_PIXELS && n < (1 << 24)) {
+            c.wide_g = (int32_t)std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
+            c.wide_off = p->n_wide; p->n_wide += SDSM_WIDE_SYNC + (int64_t)2 * c.wide_g * SDSM_WIDE_PBUF;
+        } else { c.wide_g = 0; c.wide_off = -1; }
         c.perm_inv = perm_inverse((uint32_t)std::max<long>(N, 1));
         p->mask_info[4 * i] = r0; p->mask_info[4 * i + 1] = c0; p->mask_info[4 * i + 2] = c.h; p->mask_info[4 * i + 3] = c.w;
         p->mask_off_bytes[i] = c.mask_off * 4; p->xi_off[i] = c.xi_off; p->n_pixels[i] = c.N;
@@ -207,6 +210,10 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     // their own (shorter) launch lists instead of n workgroups that exit immediately
     for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_K1_DENSE_N || p->cand[p->order[k]].N > SDSM_WIDE_PIXELS) { p->order.push_back(p->order[k]); p->n_order_c++; }
     for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_ENV_DENSE_N) { p->order.push_back(p->order[k]); p->n_order_d++; }
+    for (int k = 0; k < n; k++) {
+        const int ci = p->order[k];
+        for (int g = 0; g < p->cand[ci].wide_g; g++) { p->order.push_back(ci | (g << 24)); p->n_order_w++; }
+    }
     // workspace layout
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
@@ -230,6 +237,7 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->off_env_fst = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1));      // n_hglob counts doubles
+    p->off_wide = take(8 * (size_t)std::max<int64_t>(p->n_wide, 1));        // n_wide counts doubles
     p->total = o;
     return p;
 }
@@ -345,7 +353,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.hess_thr = SDSM_HESS_THR;
     P.psf = (const float *)(b + p->off_psf);
     P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
-    P.hglob = (double *)(b + p->off_hglob);
+    P.hglob = (double *)(b + p->off_hglob); P.wide_pool = (double *)(b + p->off_wide);
     P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
@@ -360,7 +368,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
         g_sides.emplace_back(s, n);
         ss = &g_sides.back().second;
     }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], ss->side[2], ss->fj, p->n_order_c, p->n_order_d)) != hipSuccess) return hipfail(e, "launch solve");
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], ss->side[2], ss->fj, p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }

@@ -27,6 +27,13 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
 #define SDSM_K1_NMAX 128           // solve class 1: 6 + M <= 128 and envelope <= SDSM_K1_EMAX doubles (LDS ~ 30 KB)
 #define SDSM_K1_EMAX 2560
+// Very large regions are solved by a GROUP of workgroups (2 .. 8, one per 8192 pixels): each takes a slice of the pixels in
+// every pass and the partial sums / gradient / Hessian are all-reduced through global memory (sdsm_solve.hip, WIDE).
+#define SDSM_WIDE_MIN_PIXELS 12288
+#define SDSM_WIDE_SLICE 8192
+#define SDSM_WIDE_MAX_G 8
+#define SDSM_WIDE_SYNC 16           // doubles reserved for the group's counters at the start of its pool block
+#define SDSM_WIDE_PBUF (SDSM_K2_EMAX + SDSM_MAX_N_SOLVE + 64)   // doubles one workgroup publishes per all-reduce
 #define SDSM_WIDE_PIXELS 3072       // latency mode: larger regions go to class 2 (512 threads per candidate; a batch is as slow as its slowest candidate)
 #define SDSM_K2_EMAX 11000         // solve class 2: 6 + M <= SDSM_MAX_N_SOLVE and envelope <= 11000 doubles (LDS ~ 157 KB)
 #define SDSM_K1_DENSE_N 70         // 6 + M <= 70: even a dense triangle fits class 1
@@ -59,8 +66,9 @@ struct CandDesc {
     int32_t fp_off, fp_len; // footprint labels
     int32_t Mcap;       // upper bound of M
     uint32_t perm_inv;  // crop position of the pixel with raster rank i is (i * perm_inv) mod N (low-discrepancy scatter)
-    int32_t pad;
+    int32_t wide_g;     // > 0: solved by a group of this many workgroups (regions of more than SDSM_WIDE_MIN_PIXELS pixels)
     int64_t hglob_off;  // first double of its block in the global Hessian pool (a dense triangle of 6 + min(Mcap, 1018) unknowns; only if 6 + Mcap > SDSM_ENV_DENSE_N: the envelope may not fit LDS), else -1
+    int64_t wide_off;   // first double of the group's block in the wide pool: SDSM_WIDE_SYNC + 2 * wide_g * SDSM_WIDE_PBUF doubles; else -1
 };
 
 // Written by the setup kernel.
@@ -78,7 +86,7 @@ struct CandState {
     int32_t gcount[8];  // gcount[j] = crop positions whose row has more than 4 j entries (positions are sorted by that)
 };
 static_assert(sizeof(CandState) == 104 && SDSM_ELL_GROUPS_REG <= 8, "CandState layout");
-static_assert(sizeof(CandDesc) == 80, "CandDesc layout");
+static_assert(sizeof(CandDesc) == 88, "CandDesc layout");
 
 struct BatchParams {
     int32_t n, H, W, n_atoms;
@@ -113,6 +121,7 @@ struct BatchParams {
     int32_t *env_fst;
     int32_t *env_rb;
     const float *psf;
+    double *wide_pool;                 // sync words and all-reduce buffers of the workgroup groups (CandDesc.wide_off)
     double *hglob;                     // Hessian pool of the global-memory class (envelope too large for LDS), CandDesc.hglob_off
     long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 16 cycle counters per candidate (solve kernel)
     long long *prof2;                  // diagnostic build only: 8 cycle counters per candidate (setup kernel), behind the 16 n solve counters

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     const CandDesc cd = P.cand[ci];
     CandState *st = &P.state[ci];
 
+    if (cd.wide_g > 0 && tid < 2 * SDSM_WIDE_SYNC) reinterpret_cast<int *>(P.wide_pool + cd.wide_off)[tid] = 0;   // counters of the workgroup group
     if (cd.h > SDSM_MAX_BBOX_DIM || cd.w > SDSM_MAX_BBOX_DIM || cd.N <= 0) {
         if (tid == 0) { CandState s = {}; s.status = cd.N <= 0 ? ST_ERROR : ST_UNSUPPORTED; *st = s; }
         return;

@@ -89,6 +89,9 @@ struct Cand {                       // per-candidate global pointers (already of
     int gcount[SDSM_ELL_GROUPS_REG];    // positions [0, gcount[j]) have rows of more than 4 j entries
     double *hglob;                      // flat pointer: Hessian of the global-memory class
     int N, zmax, hzmax, env_size;
+    int p_lo, p_hi;                     // the crop positions this workgroup covers in a pass (the whole crop unless it is one of a group)
+    int wg, wG;                         // member index and size of the workgroup group (wG = 1: none)
+    double *wpool;                      // the group's block of BatchParams.wide_pool
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
 };
@@ -113,6 +116,7 @@ __device__ __forceinline__ Cand uniform_cand(const Cand &c)
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) u.gcount[j] = uni(c.gcount[j]);
     u.hglob = (double *)uni((unsigned long long)c.hglob);
     u.N = uni(c.N); u.zmax = uni(c.zmax); u.hzmax = uni(c.hzmax); u.env_size = uni(c.env_size);
+    u.p_lo = uni(c.p_lo); u.p_hi = uni(c.p_hi); u.wg = uni(c.wg); u.wG = uni(c.wG); u.wpool = (double *)uni((unsigned long long)c.wpool);
     u.rmid = uni(c.rmid); u.cmid = uni(c.cmid); u.inv_hr = uni(c.inv_hr); u.inv_hc = uni(c.inv_hc);
     u.scale = uni(c.scale); u.epsilon = uni(c.epsilon); u.alpha = uni(c.alpha);
     return u;
@@ -124,6 +128,61 @@ template <class L> __device__ __forceinline__ double *hess_ptr(const Cand &c) { 
 #define RBP ((int *)(SD + L::IB))              // rb[i]: entry (i, j) of the Hessian / factor is at rb[i] + j (logical order)
 #define FSTP (RBP + L::W)                      // fst[i]: first stored column of row i (0 for the theta rows)
 #define RENDP (FSTP + L::W)                    // rend[p]: last xi row that has entries in the columns of panel p
+
+// ---- workgroup groups (WIDE): wG workgroups solve one very large candidate.  Every member runs the whole solver on its
+// own copy of the state; only the passes over the pixels are shared: a member covers crop positions [p_lo, p_hi) and the
+// partial sums are ALL-REDUCED through global memory -- every member publishes its partials, the group meets at a
+// barrier, every member adds the wG partials in the same order, so all copies stay bit-identical and take the same
+// branches.  Barrier: a monotonic counter, arrival = agent-scope release add by one lane after the workgroup barrier,
+// wait = agent-scope acquire loads by that lane (the members sit on different XCDs, whose L2s are not coherent), with a
+// time limit: a member that waits longer than ~2 s flags the group and every member gives the candidate up (status
+// error) instead of hanging.  Two publication slots alternate: a member can be at most one all-reduce ahead.
+#define WIDE_PHASE (reinterpret_cast<int *>(SD + L::FLAG) + 2)   // all-reduces done so far (LDS, uniform)
+
+template <class L>
+__device__ __forceinline__ bool wide_barrier(const Cand &c, int phase0)
+{
+    int *sync = reinterpret_cast<int *>(c.wpool);            // [0] arrivals, [1] error flag
+    __syncthreads();                                         // everybody has read the phase and published its data
+    const int phase = phase0 + 1;
+    if (threadIdx.x == 0) {
+        *WIDE_PHASE = phase;
+        __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = phase * c.wG;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (wall_clock64() - t0 > 200000000ll) { __hip_atomic_store(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // 100 MHz clock: 2 s
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    return __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+// All-reduce of up to three LDS (or global) arrays of doubles, in place.  Returns false if the group was given up.
+template <class L>
+__device__ __forceinline__ bool wide_allreduce(const Cand &c, double *a0, int n0, double *a1 = nullptr, int n1 = 0, double *a2 = nullptr, int n2 = 0)
+{
+    if (c.wG <= 1) return true;
+    const int phase = *WIDE_PHASE;
+    double *slot = c.wpool + SDSM_WIDE_SYNC + (size_t)(phase & 1) * c.wG * SDSM_WIDE_PBUF;
+    double *mine = slot + (size_t)c.wg * SDSM_WIDE_PBUF;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n0; e += L::WGS) mine[e] = a0[e];
+    for (int e = tid; e < n1; e += L::WGS) mine[n0 + e] = a1[e];
+    for (int e = tid; e < n2; e += L::WGS) mine[n0 + n1 + e] = a2[e];
+    const bool ok = wide_barrier<L>(c, phase);
+    const int nt = n0 + n1 + n2;
+    for (int e = tid; e < nt; e += L::WGS) {
+        double v = 0;
+        for (int m = 0; m < c.wG; m++) v += slot[(size_t)m * SDSM_WIDE_PBUF + e];
+        if (!ok) v = NAN;                                        // group given up: every member sees non-finite values and fails the solve
+        if (e < n0) a0[e] = v; else if (e < n0 + n1) a1[e - n0] = v; else a2[e - n0 - n1] = v;
+    }
+    __syncthreads();
+    return ok;
+}
 
 // ---- logistic loss without the math library: the passes are instruction-issue bound and a pixel costs 1 (full pass) or 8
 // (line-search sweep) evaluations of log(1 + exp(-t)); libm's exp + log are ~100 FP64 instructions, these ~55.
@@ -282,7 +341,7 @@ __device__ __noinline__ double eval_value(const Cand &c_in, int xo_in, int M_in)
     const int M = uni(M_in);
     const double *xv = SD + xo;
     double psi = 0;
-    for (int p = threadIdx.x; p < c.N; p += L::WGS) {
+    for (int p = c.p_lo + threadIdx.x; p < c.p_hi; p += L::WGS) {
         double yv = c.crop_y[p];
         uint32_t rc = c.crop_rc[p];
         double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
@@ -291,6 +350,15 @@ __device__ __noinline__ double eval_value(const Cand &c_in, int xo_in, int M_in)
         psi += softplus_neg(yv * S);
     }
     psi = block_sum<L::NWAVES>(psi, SD + L::RED);
+    if (c.wG > 1) {
+        double *tmp = SD + L::TMP;
+        __syncthreads();
+        if (threadIdx.x == 0) tmp[0] = psi;
+        __syncthreads();
+        wide_allreduce<L>(c, tmp, 1);
+        psi = tmp[0];
+        __syncthreads();
+    }
     if (M > 0) {                                         // dsm.py:323-331
         double s2 = 0;
         for (int j = threadIdx.x; j < M; j += L::WGS) s2 += sqrt(xv[6 + j] * xv[6 + j] + c.epsilon);
@@ -320,7 +388,7 @@ __device__ __noinline__ void eval_line(const Cand &c_in, int M_in, double t0_in,
 #pragma unroll
     for (int k = 0; k < LS_K; k++) ps[k] = 0;
     const bool in_regs = c.zmax <= ZREG;
-    for (int p = tid; p < c.N; p += L::WGS) {
+    for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
         const double yv = c.crop_y[p];
         const uint32_t rc = c.crop_rc[p];
         const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
@@ -362,6 +430,21 @@ __device__ __noinline__ void eval_line(const Cand &c_in, int M_in, double t0_in,
         }
     }
     block_sum_vec<LS_K, L::NWAVES>(ps, SD + L::RED);
+    if (c.wG > 1) {
+        double *tmp = SD + L::TMP;
+        __syncthreads();
+        if (tid < LS_K) {
+            double v = 0;
+#pragma unroll
+            for (int k = 0; k < LS_K; k++) v = tid == k ? ps[k] : v;
+            tmp[tid] = v;
+        }
+        __syncthreads();
+        wide_allreduce<L>(c, tmp, LS_K);
+#pragma unroll
+        for (int k = 0; k < LS_K; k++) ps[k] = tmp[k];
+        __syncthreads();
+    }
     if (M > 0) {                                         // dsm.py:323-331
         double rs[LS_K];
 #pragma unroll
@@ -415,7 +498,7 @@ __device__ __noinline__ double eval_full_ell(const Cand &c_in PROF_PARAM)
     double red[28];
 #pragma unroll
     for (int k = 0; k < 28; k++) red[k] = 0;
-    for (int p = tid; p < c.N; p += L::WGS) {
+    for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
         const double yv = c.crop_y[p];
         const uint32_t rc = c.crop_rc[p];
         const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
@@ -435,8 +518,16 @@ __device__ __noinline__ double eval_full_ell(const Cand &c_in PROF_PARAM)
     block_sum_scatter<28, L::NWAVES>(red, SD + L::RED);
     if (tid < 6) g[tid] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 1 + tid);
     if (tid < 21) Hp[tid] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 7 + tid);   // packed lower triangle of a 6x6 matrix = the same enumeration order
-    const double psi = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 0);
+    double psi = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 0);
     __syncthreads();
+    if (c.wG > 1) {
+        double *tmp = SD + L::TMP;
+        if (tid == 0) tmp[0] = psi;
+        __syncthreads();
+        wide_allreduce<L>(c, Hp, 21, g, 6, tmp, 1);
+        psi = tmp[0];
+        __syncthreads();
+    }
     PROF_ADD(2, pt);
     return psi;
 }
@@ -466,7 +557,7 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M_in PROF_
     for (int k = 0; k < 28; k++) red[k] = 0;
     const int zm = M > 0 ? c.zmax : 0;
     const bool in_regs = zm <= ZREG;
-    for (int p = tid; p < c.N; p += L::WGS) {
+    for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
         FINE_START();
         double yv = c.crop_y[p];
         uint32_t rc = c.crop_rc[p];
@@ -561,6 +652,14 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M_in PROF_
     }
     double psi = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 0);
     __syncthreads();
+    if (c.wG > 1) {                                      // partial Hessian / gradient / psi of this member's slice -> totals
+        double *tmp = SD + L::TMP;
+        if (tid == 0) tmp[0] = psi;
+        __syncthreads();
+        wide_allreduce<L>(c, Hp, c.env_size, g, n, tmp, 1);
+        psi = tmp[0];
+        __syncthreads();
+    }
     if (M > 0) psi += add_regulariser<L>(c, M);
     __syncthreads();
     PROF_ADD(2, pt);
@@ -949,13 +1048,16 @@ __device__ __forceinline__ void reparam(const double *th, double p0, double p1, 
 // A candidate belongs to the FIRST class whose limits (6 + M <= NMAX and Hessian envelope <= EMAX doubles) it meets; the
 // limits of the previous class are passed at run time (nprev = 0 for the first class).  The first class also writes the
 // records of trivial / failed-setup candidates.
-template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256>
+// WIDE: the launch list holds (candidate | member << 24) for every member of every workgroup group.
+template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false>
 __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records,
                                                               uint32_t *masks, double *xi_out)
 {
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
     const int tid = threadIdx.x;
-    const int ci = P.order[blockIdx.x];
+    const int entry = P.order[blockIdx.x];
+    const int ci = WIDE ? entry & 0xffffff : entry;
+    const int wg = WIDE ? (entry >> 24) & 0xff : 0;
     const CandDesc cd = P.cand[ci];
     const CandState st = P.state[ci];
     sdsm_record *rec = &records[ci];
@@ -974,8 +1076,14 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     if (6 + Mfull > SDSM_MAX_N_SOLVE) { unsupported = true; Mfull = 0; }     // elliptical result only (flagged)
     const int nfull = 6 + Mfull;
     const int efull = Mfull > 0 ? st.env_size : 21;
-    if (nfull <= nprev && efull <= eprev && cd.N <= pixprev) return;         // an earlier class took it
-    if (!(nfull <= NMAX && efull <= EMAX && cd.N <= pixmax)) return;         // a later class takes it
+    if (WIDE) {
+        if (!(nfull <= NMAX && efull <= EMAX)) return;                       // its envelope does not fit: left to the global-memory class
+    } else {
+        const bool to_group = cd.wide_g > 0 && nfull <= SDSM_MAX_N_SOLVE && efull <= SDSM_K2_EMAX;
+        if (to_group) return;                                                // solved by its workgroup group
+        if (nfull <= nprev && efull <= eprev && cd.N <= pixprev) return;     // an earlier class took it
+        if (!(nfull <= NMAX && efull <= EMAX && cd.N <= pixmax)) return;     // a later class takes it
+    }
     if (GLOBALH && cd.hglob_off < 0) {                          // cannot happen (the host reserves a slot whenever Mcap admits it)
         if (tid == 0) { sdsm_record r0 = {}; r0.status = SDSM_CAND_UNSUPPORTED; r0.n_pixels = cd.N; r0.n_deform = st.M; *rec = r0; }
         return;
@@ -983,6 +1091,18 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 
     Cand c;
     c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0; c.hzmax = Mfull > 0 ? st.hzmax : 0; c.env_size = 21;
+    c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr;
+    if (WIDE) {
+        c.wG = cd.wide_g; c.wg = wg; c.wpool = P.wide_pool + cd.wide_off;
+        const int chunk = (((cd.N + c.wG - 1) / c.wG) + 63) & ~63;           // slices start at multiples of 64 (row-group logic of load_row)
+        c.p_lo = wg * chunk < cd.N ? wg * chunk : cd.N;
+        c.p_hi = c.p_lo + chunk < cd.N ? c.p_lo + chunk : cd.N;
+    }
+    if (tid == 0) *WIDE_PHASE = 0;
+    if (WIDE && wg == 0) {                                               // cleared here: the members set bits at the very end, after many group barriers
+        uint32_t *mk0 = masks + cd.mask_off;
+        for (int i = tid; i < (cd.h * cd.w + 31) / 32; i += L::WGS) mk0[i] = 0;
+    }
     c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
     c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
 #pragma unroll
@@ -1100,12 +1220,12 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     // ---- mask tail (objects.py:198-209) ----------------------------------------------------------
     const int mwords = (cd.h * cd.w + 31) / 32;
     uint32_t *mk = masks + cd.mask_off;
-    for (int i = tid; i < mwords; i += L::WGS) mk[i] = 0;
+    if (!WIDE) for (int i = tid; i < mwords; i += L::WGS) mk[i] = 0;         // (a group's member 0 cleared it before the first all-reduce)
     __syncthreads();
     int rmin = 1 << 30, rmax = -1, cmin = 1 << 30, cmax = -1;
     int onb = 0;
     if (status_final != SDSM_CAND_ERROR) {
-        for (int p = tid; p < c.N; p += L::WGS) {
+        for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
             uint32_t rc = c.crop_rc[p];
             int pr = rc >> 16, pc = rc & 0xffffu;
             double u = ((double)pr - c.rmid) * c.inv_hr, v = ((double)pc - c.cmid) * c.inv_hc;
@@ -1135,6 +1255,20 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     rmin = block_min_i32<L::NWAVES>(rmin, ired); cmin = block_min_i32<L::NWAVES>(cmin, ired);
     rmax = -block_min_i32<L::NWAVES>(-rmax, ired); cmax = -block_min_i32<L::NWAVES>(-cmax, ired);
     onb = -block_min_i32<L::NWAVES>(-onb, ired);
+    if (WIDE) {                                                              // bounding box over the members' slices
+        const int phase = *WIDE_PHASE;
+        double *slot = c.wpool + SDSM_WIDE_SYNC + (size_t)(phase & 1) * c.wG * SDSM_WIDE_PBUF;
+        int *mine = reinterpret_cast<int *>(slot + (size_t)c.wg * SDSM_WIDE_PBUF);
+        if (tid == 0) { mine[0] = rmin; mine[1] = cmin; mine[2] = rmax; mine[3] = cmax; }
+        const bool okw = wide_barrier<L>(c, phase);
+        for (int m = 0; m < c.wG; m++) {
+            const int *o = reinterpret_cast<const int *>(slot + (size_t)m * SDSM_WIDE_PBUF);
+            rmin = o[0] < rmin ? o[0] : rmin; cmin = o[1] < cmin ? o[1] : cmin;
+            rmax = o[2] > rmax ? o[2] : rmax; cmax = o[3] > cmax ? o[3] : cmax;
+        }
+        if (!okw) status_final = SDSM_CAND_ERROR;                            // the group was given up (a member waited too long)
+        if (c.wg != 0) return;                                               // member 0 writes the record
+    }
 
     if (xi_out) for (int j = tid; j < st.M; j += L::WGS) xi_out[cd.xi_off + j] = j < Mfull ? x[6 + j] : 0;
     if (tid == 0) {
@@ -1161,10 +1295,10 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 // class 2: 6 + M <= 1024, envelope <= 11000 doubles 512 threads, LDS ~ 157 KB (1 workgroup / CU)
 // class 3: 6 + M <= 1024, any envelope              512 threads, Hessian in global memory (only launched when needed)
 // The classes are independent: they run concurrently on streams forked from the caller's stream.
-template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256>
+template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false>
 static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
-    auto kern = sdsm_k_solve<NMAX, EMAX, WPE, GLOBALH, WGSIZE>;
+    auto kern = sdsm_k_solve<NMAX, EMAX, WPE, GLOBALH, WGSIZE, WIDE>;
     constexpr int lds = Lay<NMAX, EMAX, GLOBALH, WGSIZE>::TOTAL_BYTES;
     static_assert(lds <= 160 * 1024 - 512, "LDS budget");
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1176,16 +1310,21 @@ static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int p
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
                                         hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */,
-                                        int n_c, int n_d)
+                                        int n_c, int n_d, int n_w)
 {
-    (void)side2;
     hipError_t e;
     // launch lists: P.order = [all n | the n_c candidates whose bound Mcap admits more than class 1 | the n_d that admit more than class 2]
-    BatchParams Pc = P, Pd = P;
+    BatchParams Pc = P, Pd = P, Pw = P;
     Pc.order = P.order + P.n; Pc.n = n_c;
     Pd.order = P.order + P.n + n_c; Pd.n = n_d;
+    Pw.order = P.order + P.n + n_c + n_d; Pw.n = n_w;                         // (candidate | member << 24) of the workgroup groups
     // fork: the side streams wait for everything queued on the caller's stream so far (setup kernel)
-    if (n_c > 0 || n_d > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
+    if (n_c > 0 || n_d > 0 || n_w > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
+    if (n_w > 0) {   // very large regions: groups of 512-thread workgroups, launched first (the longest chains of the batch)
+        if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true>(Pw, 0, 0, 0, INT_MAX, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
+    }
     // classes 2 and 3 share ONE side stream (they are short lists that mostly exit at once; every extra stream per batch
     // costs a hardware queue, and batches in flight beyond the queues serialise)
     (void)side3;
@@ -1198,5 +1337,6 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 2>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
     if ((n_c > 0 || n_d > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
+    if (n_w > 0 && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
     return hipSuccess;
 }
