@@ -53,6 +53,9 @@ if p[:, 8:12].sum() > 0 and p[:, 13:16].sum() > 0:
 if ps.sum() > 0:
     names_s = ['region scan', 'compressed coords + lattice', 'greedy grid', 'grid sort + row table', 'row lengths + counting sort', 'rows of G~ (2 passes)', 'envelope + state']
     print('setup kernel, thread 0, share of its time: ' + ',  '.join('%s %.1f%%' % (nm, 100 * ps[:, k].sum() / ps.sum()) for k, nm in enumerate(names_s)) + '   (median total %.0f us)' % (np.median(ps.sum(1)) / 2400))
+if ps.sum() > 0:
+    kbig = int(np.argmax(ps.sum(1)))
+    print('slowest setup: cand %d N=%d M=%d total %.2f ms: ' % (kbig, recs['n_pixels'][kbig], recs['n_deform'][kbig], ps[kbig].sum() / 2.4e6) + ', '.join('%s %.2f' % (nm, ps[kbig, k] / 2.4e6) for k, nm in enumerate(names_s)))
 print('slowest candidates:')
 for k in worst:
     print('  cand %d N=%d M=%d it_ell=%d it_dsm=%d evals=%d/%d total=%.2f ms  A=%.2f B=%.2f red=%.2f fac=%.2f ls=%.2f' % (
