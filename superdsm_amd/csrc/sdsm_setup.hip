@@ -308,7 +308,8 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     const int ngmax = P.zcap / 4;                        // P.zcap is a multiple of 4, <= 4 * SDSM_MAX_ELL_GROUPS
     for (int k = tid; k <= ngmax; k += SDSM_WG) { cls_cnt[k] = 0; cls_run[k] = 0; }
     __syncthreads();
-    for (int i = tid; i < cd.N; i += SDSM_WG) {
+    for (int q = tid; q < cd.N; q += SDSM_WG) {           // raster order (coherent wavefronts), see step 5
+        const int i = (int)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N);
         uint32_t key = P.crop_cc[cd.crop_off + i];
         const int cr = key >> 16, cc = key & 0xffffu;
         int cnt = 0;
