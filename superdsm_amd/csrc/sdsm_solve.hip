@@ -135,7 +135,7 @@ template <class L> __device__ __forceinline__ double *hess_ptr(const Cand &c) { 
 // barrier, every member adds the wG partials in the same order, so all copies stay bit-identical and take the same
 // branches.  Barrier: a monotonic counter, arrival = agent-scope release add by one lane after the workgroup barrier,
 // wait = agent-scope acquire loads by that lane (the members sit on different XCDs, whose L2s are not coherent), with a
-// time limit: a member that waits longer than ~2 s flags the group and every member gives the candidate up (status
+// time limit: a member that waits longer than ~10 s flags the group and every member gives the candidate up (status
 // error) instead of hanging.  Two publication slots alternate: a member can be at most one all-reduce ahead.
 #define WIDE_PHASE (reinterpret_cast<int *>(SD + L::FLAG) + 2)   // all-reduces done so far (LDS, uniform)
 
@@ -152,7 +152,7 @@ __device__ __forceinline__ bool wide_barrier(const Cand &c, int phase0)
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            if (wall_clock64() - t0 > 200000000ll) { __hip_atomic_store(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // 100 MHz clock: 2 s
+            if (wall_clock64() - t0 > 1000000000ll) { __hip_atomic_store(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // constant 100 MHz clock: 10 s
             __builtin_amdgcn_s_sleep(8);
         }
     }
