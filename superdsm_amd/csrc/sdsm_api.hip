@@ -17,7 +17,8 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
-extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream);
+extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream,
+                                        const int32_t *order_w, int n_w);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -357,7 +358,7 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    if ((e = sdsm_launch_setup(P, d_y, d_atoms, d_valid, s)) != hipSuccess) return hipfail(e, "launch setup");
+    if ((e = sdsm_launch_setup(P, (const double *)d_y, (const int32_t *)d_atoms, (const uint8_t *)d_valid, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch setup");
     if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     SideSet *ss = nullptr;
     for (auto &kv : g_sides) if (kv.first == s) ss = &kv.second;

@@ -95,6 +95,76 @@ __device__ __forceinline__ int cheb(int r0, int c0, int r1, int c1)
     return a > b ? a : b;
 }
 
+// Rows of G~ for the raster ranks [q0, q1) of a candidate: PSF gather, float32 pairwise row sum, float32 division
+// (dsm.py:192-193), entries written once into their final slots.  Pixels are taken in RASTER order (rank q -> scan index
+// q * perm_inv mod N): the 64 lanes of a wavefront then sit next to each other in the image, see (almost) the same grid
+// points and take the same branches in the loops over them; in crop order they are scattered and every lane's hits are
+// paid for by all (measured 3x on 73 k-pixel regions).  efirst (LDS, M ints, initialised to j): first coupled column.
+__device__ __forceinline__ void rows_of_ranks(const BatchParams &P, const CandDesc &cd, int M, int R, int hc, const uint32_t *gridkeys,
+                                              const uint16_t *growstart, const float *psf_lds, int *efirst, int q0, int q1, int step,
+                                              bool &bad, int &hzmax)
+{
+    for (int q = q0; q < q1; q += step) {
+        const int i = (int)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N);
+        const int pos = (int)P.dist[cd.crop_off + i];
+        uint32_t key = P.crop_cc[cd.crop_off + i];
+        // pass 1 over the grid points: row sum in numpy's order, largest entry, number of entries (nothing is stored)
+        WeightCtx c;
+        c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.psf_lds = psf_lds; c.keys = gridkeys; c.nnz = 0; c.wmax = 0.f;
+        c.jlo = growstart[c.cr - R > 0 ? c.cr - R : 0]; c.jhi = c.cr + R + 1 < hc ? growstart[c.cr + R + 1] : M;
+        const int64_t base = cd.ell_off + (int64_t)pos * 4;
+        P.crop_y[cd.crop_off + pos] = P.tmp_y[cd.crop_off + i];
+        P.crop_rc[cd.crop_off + pos] = P.tmp_rc[cd.crop_off + i];
+        const float sum = pw_sum(c, M);
+        if (c.nnz > P.zcap || !(sum > 0.f)) { bad = true; P.ell_meta[cd.crop_off + pos] = 0; continue; }   // dsm.py:194
+        // pass 2: normalised entries written once, straight into their final slots: entries >= hess_thr * row maximum (the
+        // solver's approximate Hessian uses only those; S and the gradient use all) from slot 0 upwards -- in ascending
+        // column order, so the solve kernel knows which of a pair is the row --, the others from slot nnz - 1 downwards
+        const float lim = P.hess_thr * __fdiv_rn(c.wmax, sum);
+        int hz = 0, others = 0, mn = 0;
+        for (int j = c.jlo; j < c.jhi; j++) {
+            const uint32_t gk = gridkeys[j];
+            int dr = (int)(gk >> 16) - c.cr, dc = (int)(gk & 0xffffu) - c.cc;
+            const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
+            if (adr > R || adc > R) continue;
+            const int pidx = (R + dr) * P.k + (R + dc);
+            const float nw = __fdiv_rn(psf_lds ? psf_lds[pidx] : P.psf[pidx], sum);
+            int slot;
+            if (!(nw < lim)) {
+                slot = hz++;
+                // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
+                if (slot == 0) mn = j; else atomicMin(&efirst[j], mn);
+            } else slot = c.nnz - 1 - others++;
+            const int64_t e = ell_at(base, cd.N, slot);
+            P.ell_idx[e] = (uint16_t)j; P.ell_w[e] = nw;
+        }
+        // padding (index 0, weight 0) up to the group count of the first position of this pixel's 64-position chunk (a
+        // wavefront of the solve kernel reads the groups its first lane needs for all of its lanes): P.inv[chunk]
+        const int kh = (int)P.inv[cd.crop_off + (pos >> 6)];
+        for (int sl = c.nnz; sl < 4 * kh; sl++) {
+            const int64_t e = ell_at(base, cd.N, sl);
+            P.ell_idx[e] = 0; P.ell_w[e] = 0.f;
+        }
+        P.ell_meta[cd.crop_off + pos] = (uint32_t)c.nnz | ((uint32_t)hz << 16);
+        hzmax = hz > hzmax ? hz : hzmax;
+    }
+}
+
+// Envelope storage of the Hessian (BatchParams.env_fst / env_rb) from the first coupled columns: made non-decreasing and
+// multiples of SDSM_PANEL (the factorisation works on panels of that many columns), row bases by a running sum.  One thread.
+__device__ __forceinline__ int envelope_from_first(const BatchParams &P, const CandDesc &cd, int M, int *efirst)
+{
+    int run = M;
+    for (int a = M - 1; a >= 0; a--) { run = efirst[a] < run ? efirst[a] : run; efirst[a] = run & ~(SDSM_PANEL - 1); }
+    int rp = 0;
+    for (int a = 0; a < M; a++) {
+        P.env_fst[cd.xi_off + a] = efirst[a];
+        P.env_rb[cd.xi_off + a] = rp - efirst[a];
+        rp += a - efirst[a] + 1;
+    }
+    return rp + 6 * M + 21;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const double *__restrict__ y,
@@ -308,7 +378,8 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     const int ngmax = P.zcap / 4;                        // P.zcap is a multiple of 4, <= 4 * SDSM_MAX_ELL_GROUPS
     for (int k = tid; k <= ngmax; k += SDSM_WG) { cls_cnt[k] = 0; cls_run[k] = 0; }
     __syncthreads();
-    for (int q = tid; q < cd.N; q += SDSM_WG) {           // raster order (coherent wavefronts), see step 5
+    int cntmax = 0;
+    for (int q = tid; q < cd.N; q += SDSM_WG) {           // raster order (coherent wavefronts), see rows_of_ranks
         const int i = (int)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N);
         uint32_t key = P.crop_cc[cd.crop_off + i];
         const int cr = key >> 16, cc = key & 0xffffu;
@@ -319,6 +390,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             dr = dr < 0 ? -dr : dr; dc = dc < 0 ? -dc : dc;
             cnt += (dr <= R && dc <= R) ? 1 : 0;
         }
+        cntmax = cnt > cntmax ? cnt : cntmax;
         int k = (cnt + 3) >> 2;
         k = k > ngmax ? ngmax : k;                       // rows longer than zcap are reported as errors in step 5
         P.dist[cd.crop_off + i] = (uint32_t)k;
@@ -353,9 +425,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
             if (k >= 0) {
                 int before = 0;
                 for (int w2 = 0; w2 < wave; w2++) before += wave_cnt[w2][k];
-                const uint32_t np2 = (uint32_t)(cls_start[k] + cls_run[k] + before + within);
-                P.dist[cd.crop_off + i] = np2;
-                P.inv[cd.crop_off + np2] = (uint32_t)i;
+                P.dist[cd.crop_off + i] = (uint32_t)(cls_start[k] + cls_run[k] + before + within);
             }
             __syncthreads();
             for (int k2 = tid; k2 <= ngmax; k2 += SDSM_WG) {
@@ -371,7 +441,35 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     __syncthreads();
 
     SETUP_T(4);
-    // ---- 5. rows of G~: PSF gather, float32 pairwise row sum, float32 division (dsm.py:192-193) --
+    // group count of the first position of every 64-position chunk (padding target of its rows), for rows_of_ranks
+    for (int t = tid; t * 64 < cd.N; t += SDSM_WG) {
+        int kh = 0;
+        const int head = t * 64;
+        for (int k2 = ngmax; k2 >= 0; k2--) if (cls_cnt[k2] > 0 && head >= cls_start[k2]) kh = k2;
+        P.inv[cd.crop_off + t] = (uint32_t)kh;
+    }
+    const int zmax = -block_min_i32(-cntmax, scr32);
+    s.M = M; s.zmax = zmax; s.hzmax = 0;
+    for (int j = 0; j < 8; j++) {                        // positions [0, gcount[j]) have rows of more than 4 j entries
+        int acc = 0;
+        for (int k2 = j + 1; k2 <= ngmax; k2++) acc += cls_cnt[k2];
+        s.gcount[j] = acc;
+    }
+    __syncthreads();
+    if (cd.wide_g > 0) {
+        // a very large region: its rows are built by the members of its workgroup group (sdsm_k_setup_rows), which also
+        // finish the envelope; env_size == -1 marks the state as pending
+        for (int j = tid; j < M; j += SDSM_WG) P.env_fst[cd.xi_off + j] = j;
+        s.env_size = -1; s.status = ST_OK;
+        if (tid == 0) *st = s;
+        SETUP_T(5);
+#ifdef SDSM_PROFILE
+        if (P.prof2 && tid == 0) for (int k = 0; k < 8; k++) P.prof2[(size_t)ci * 8 + k] = sp_acc[k];
+#endif
+        return;
+    }
+
+    // ---- 5. rows of G~ ---------------------------------------------------------------------------
     const float *psf_lds = nullptr;
     if (P.k * P.k <= SDSM_PSF_LDS) {                     // the footprint bitset is no longer needed
         float *pl = reinterpret_cast<float *>(fp_or_psf);
@@ -380,80 +478,15 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         __syncthreads();
     }
     bool bad = false;
-    int zmax = 0, hzmax = 0;
-    // Pixels are taken in RASTER order (rank q -> scan index q * perm_inv mod N): the 64 lanes of a wavefront then sit next
-    // to each other in the image, see (almost) the same grid points and take the same branches in the loops over them;
-    // in crop order they are scattered and every lane's hits are paid for by all (measured 3x on 73 k-pixel regions).
-    for (int q = tid; q < cd.N; q += SDSM_WG) {
-        const int i = (int)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N);
-        const int pos = (int)P.dist[cd.crop_off + i];
-        uint32_t key = P.crop_cc[cd.crop_off + i];
-        // pass 1 over the grid points: row sum in numpy's order, largest entry, number of entries (nothing is stored)
-        WeightCtx c;
-        c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.psf_lds = psf_lds; c.keys = gridkeys; c.nnz = 0; c.wmax = 0.f;
-        c.jlo = growstart[c.cr - R > 0 ? c.cr - R : 0]; c.jhi = c.cr + R + 1 < hc ? growstart[c.cr + R + 1] : M;
-        const int64_t base = cd.ell_off + (int64_t)pos * 4;
-        P.crop_y[cd.crop_off + pos] = P.tmp_y[cd.crop_off + i];
-        P.crop_rc[cd.crop_off + pos] = P.tmp_rc[cd.crop_off + i];
-        const float sum = pw_sum(c, M);
-        if (c.nnz > P.zcap || !(sum > 0.f)) { bad = true; P.ell_meta[cd.crop_off + pos] = 0; continue; }   // dsm.py:194
-        // pass 2: normalised entries written once, straight into their final slots: entries >= hess_thr * row maximum (the
-        // solver's approximate Hessian uses only those; S and the gradient use all) from slot 0 upwards -- in ascending
-        // column order, so the solve kernel knows which of a pair is the row --, the others from slot nnz - 1 downwards
-        const float lim = P.hess_thr * __fdiv_rn(c.wmax, sum);
-        int hz = 0, others = 0, mn = 0;
-        for (int j = c.jlo; j < c.jhi; j++) {
-            const uint32_t gk = gridkeys[j];
-            int dr = (int)(gk >> 16) - c.cr, dc = (int)(gk & 0xffffu) - c.cc;
-            const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
-            if (adr > R || adc > R) continue;
-            const int pidx = (R + dr) * P.k + (R + dc);
-            const float nw = __fdiv_rn(psf_lds ? psf_lds[pidx] : P.psf[pidx], sum);
-            int slot;
-            if (!(nw < lim)) {
-                slot = hz++;
-                // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
-                if (slot == 0) mn = j; else atomicMin(&efirst[j], mn);
-            } else slot = c.nnz - 1 - others++;
-            const int64_t e = ell_at(base, cd.N, slot);
-            P.ell_idx[e] = (uint16_t)j; P.ell_w[e] = nw;
-        }
-        // padding (index 0, weight 0) up to the group count of the first position of this pixel's 64-position chunk: a
-        // wavefront of the solve kernel reads the groups its first lane needs for all of its lanes
-        int kh = 0;
-        { const int head = pos & ~63; for (int k2 = ngmax; k2 >= 0; k2--) if (cls_cnt[k2] > 0 && head >= cls_start[k2]) kh = k2; }
-        for (int sl = c.nnz; sl < 4 * kh; sl++) {
-            const int64_t e = ell_at(base, cd.N, sl);
-            P.ell_idx[e] = 0; P.ell_w[e] = 0.f;
-        }
-        P.ell_meta[cd.crop_off + pos] = (uint32_t)c.nnz | ((uint32_t)hz << 16);
-        zmax = c.nnz > zmax ? c.nnz : zmax;
-        hzmax = hz > hzmax ? hz : hzmax;
-    }
+    int hzmax = 0;
+    rows_of_ranks(P, cd, M, R, hc, gridkeys, growstart, psf_lds, efirst, tid, cd.N, SDSM_WG, bad, hzmax);
     if (bad) atomicOr(&sh_err, 1);
-    zmax = -block_min_i32(-zmax, scr32);
     hzmax = -block_min_i32(-hzmax, scr32);
     __syncthreads();
     SETUP_T(5);
-    // ---- 6. envelope storage of the Hessian (BatchParams.env_fst / env_rb): first columns made non-decreasing and
-    //      multiples of SDSM_PANEL (the factorisation works on panels of that many columns), row bases by a running sum ------------
-    if (tid == 0) {
-        int run = M;
-        for (int a = M - 1; a >= 0; a--) { run = efirst[a] < run ? efirst[a] : run; efirst[a] = run & ~(SDSM_PANEL - 1); }
-        int rp = 0;
-        for (int a = 0; a < M; a++) {
-            P.env_fst[cd.xi_off + a] = efirst[a];
-            P.env_rb[cd.xi_off + a] = rp - efirst[a];
-            rp += a - efirst[a] + 1;
-        }
-        s.env_size = rp + 6 * M + 21;
-    }
-    s.M = M; s.zmax = zmax; s.hzmax = hzmax;
-    for (int j = 0; j < 8; j++) {                        // positions [0, gcount[j]) have rows of more than 4 j entries
-        int acc = 0;
-        for (int k2 = j + 1; k2 <= ngmax; k2++) acc += cls_cnt[k2];
-        s.gcount[j] = acc;
-    }
+    // ---- 6. envelope storage of the Hessian ------------------------------------------------------
+    if (tid == 0) s.env_size = envelope_from_first(P, cd, M, efirst);
+    s.hzmax = hzmax;
     s.status = sh_err ? ST_ERROR : ST_OK;
     if (tid == 0) *st = s;
     SETUP_T(6);
@@ -462,8 +495,70 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
 #endif
 }
 
-extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream)
+// Rows of G~ and envelope of the very large regions: one workgroup per member of the region's workgroup group, each takes
+// a slice of the raster ranks.  The members meet through global atomics only (first coupled columns: atomicMin, largest
+// number of Hessian entries: atomicMax, error flag: atomicOr); the LAST member to finish (a ticket counter, no waiting)
+// builds the envelope and completes the state.
+__global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
+{
+    __shared__ uint32_t gridkeys[SDSM_MAX_N_SOLVE];
+    __shared__ uint16_t growstart[SDSM_MAX_BBOX_DIM];
+    __shared__ float psf_tab[SDSM_PSF_LDS];
+    __shared__ int efirst[SDSM_MAX_N_SOLVE];
+    __shared__ int scr32[SDSM_WAVES];
+    __shared__ int sh_last;
+    const int tid = threadIdx.x;
+    const int entry = P.order[blockIdx.x];
+    const int ci = entry & 0xffffff, g = (entry >> 24) & 0xff;
+    const CandDesc cd = P.cand[ci];
+    CandState *st = &P.state[ci];
+    if (st->status != ST_OK || st->env_size != -1) return;       // nothing pending (trivial, no G~, unsupported, ...)
+    const int M = st->M, hc = st->hc, R = P.R, G = cd.wide_g;
+    int *sync = reinterpret_cast<int *>(P.wide_pool + cd.wide_off);   // [2] ticket, [3] error flag (zeroed by sdsm_k_setup)
+    for (int j = tid; j < M; j += SDSM_WG) { gridkeys[j] = P.grid_rc[cd.xi_off + j]; efirst[j] = j; }
+    const float *psf_lds = nullptr;
+    if (P.k * P.k <= SDSM_PSF_LDS) {
+        for (int e = tid; e < P.k * P.k; e += SDSM_WG) psf_tab[e] = P.psf[e];
+        psf_lds = psf_tab;
+    }
+    __syncthreads();
+    for (int r = tid; r < hc && r < SDSM_MAX_BBOX_DIM; r += SDSM_WG) {
+        int lo = 0, hi = M;                               // first j with row(j) >= r
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(gridkeys[mid] >> 16) < r) lo = mid + 1; else hi = mid; }
+        growstart[r] = (uint16_t)lo;
+    }
+    __syncthreads();
+    const int chunk = (cd.N + G - 1) / G;
+    const int q0 = g * chunk < cd.N ? g * chunk : cd.N, q1 = q0 + chunk < cd.N ? q0 + chunk : cd.N;
+    bool bad = false;
+    int hzmax = 0;
+    rows_of_ranks(P, cd, M, R, hc, gridkeys, growstart, psf_lds, efirst, q0 + tid, q1, SDSM_WG, bad, hzmax);
+    hzmax = -block_min_i32(-hzmax, scr32);
+    __syncthreads();
+    for (int j = tid; j < M; j += SDSM_WG) if (efirst[j] < j) atomicMin(&P.env_fst[cd.xi_off + j], efirst[j]);
+    if (bad) atomicOr(&sync[3], 1);
+    if (tid == 0) atomicMax(&st->hzmax, hzmax);
+    __syncthreads();
+    if (tid == 0) sh_last = __hip_atomic_fetch_add(&sync[2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+    __syncthreads();
+    if (!sh_last) return;
+    // last member: every other member's atomics precede its ticket; read them with agent-scope loads
+    for (int j = tid; j < M; j += SDSM_WG) efirst[j] = __hip_atomic_load(&P.env_fst[cd.xi_off + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        st->env_size = envelope_from_first(P, cd, M, efirst);
+        if (__hip_atomic_load(&sync[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) st->status = ST_ERROR;
+    }
+}
+
+extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream,
+                                        const int32_t *order_w, int n_w)
 {
     hipLaunchKernelGGL(sdsm_k_setup, dim3(P.n), dim3(SDSM_WG), 0, stream, P, d_y, d_atoms, d_valid);
+    if (n_w > 0) {                                       // (candidate | member << 24) of the workgroup groups
+        BatchParams Pw = P;
+        Pw.order = order_w; Pw.n = n_w;
+        hipLaunchKernelGGL(sdsm_k_setup_rows, dim3(n_w), dim3(SDSM_WG), 0, stream, Pw);
+    }
     return hipGetLastError();
 }
