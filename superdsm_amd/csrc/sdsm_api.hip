@@ -146,6 +146,60 @@ static uint32_t perm_inverse(uint32_t N)
     return (uint32_t)t;
 }
 
+// Workgroup groups, launch lists and workspace layout (repeated when the scheduling mode changes).
+static void layout_plan(sdsm_plan *p)
+{
+    const int n = p->n;
+    const bool latency = p->wide_pixels != INT_MAX;
+    p->n_wide = 0;
+    for (int i = 0; i < n; i++) {
+        CandDesc &c = p->cand[i];
+        long G = 0;
+        if (n < (1 << 24)) {
+            if (c.N > SDSM_WIDE_MIN_PIXELS) G = std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (c.N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
+            else if (latency && c.N > SDSM_WIDE_PIXELS) G = std::min<long>(4, std::max<long>(2, (c.N + 2047) / 2048));   // latency mode: the largest regions of an ordinary image too
+        }
+        if (G > 0) { c.wide_g = (int32_t)G; c.wide_off = p->n_wide; p->n_wide += SDSM_WIDE_SYNC + (int64_t)2 * G * SDSM_WIDE_PBUF; }
+        else { c.wide_g = 0; c.wide_off = -1; }
+    }
+    p->n_order_c = p->n_order_d = p->n_order_w = 0;
+    p->order.resize(n);
+    std::iota(p->order.begin(), p->order.end(), 0);
+    std::stable_sort(p->order.begin(), p->order.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
+    // a candidate can only belong to a larger size class if its upper bound Mcap allows it: the larger classes get
+    // their own (shorter) launch lists instead of n workgroups that exit immediately
+    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_K1_DENSE_N || p->cand[p->order[k]].N > SDSM_WIDE_PIXELS) { p->order.push_back(p->order[k]); p->n_order_c++; }
+    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_ENV_DENSE_N) { p->order.push_back(p->order[k]); p->n_order_d++; }
+    for (int k = 0; k < n; k++) {
+        const int ci = p->order[k];
+        for (int g = 0; g < p->cand[ci].wide_g; g++) { p->order.push_back(ci | (g << 24)); p->n_order_w++; }
+    }
+    // workspace layout
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+    p->off_cand = take(sizeof(CandDesc) * std::max(n, 1));
+    p->off_state = take(sizeof(CandState) * std::max(n, 1));
+    p->off_fp = take(4 * std::max<size_t>(p->fp_labels.size(), 1));
+    p->off_order = take(4 * std::max<size_t>(p->order.size(), 1));
+    p->off_psf = take(4 * p->psf.size());
+    size_t np = (size_t)std::max<int64_t>(p->total_pixels, 1);
+    p->off_crop_y = take(8 * np);
+    p->off_crop_rc = take(4 * np);
+    p->off_crop_cc = take(4 * np);
+    p->off_dist = take(4 * np);
+    p->off_tmp_y = take(8 * np);
+    p->off_tmp_rc = take(4 * np);
+    p->off_inv = take(4 * np);
+    p->off_ell_meta = take(4 * np);
+    p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
+    p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
+    p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
+    p->off_env_fst = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
+    p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
+    p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1));      // n_hglob counts doubles
+    p->off_wide = take(8 * (size_t)std::max<int64_t>(p->n_wide, 1));        // n_wide counts doubles
+    p->total = o;
+}
 extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t *atom_stats, const sdsm_dsm_config *cfg,
                                        int n, const int32_t *offsets, const int32_t *labels)
 {
@@ -196,50 +250,11 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
             const int64_t nn = 6 + std::min<int64_t>(c.Mcap, SDSM_MAX_N_SOLVE - 6);
             c.hglob_off = p->n_hglob; p->n_hglob += nn * (nn + 1) / 2;
         } else c.hglob_off = -1;
-        if (N > SDSM_WIDE_MIN_PIXELS && n < (1 << 24)) {
-            c.wide_g = (int32_t)std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
-            c.wide_off = p->n_wide; p->n_wide += SDSM_WIDE_SYNC + (int64_t)2 * c.wide_g * SDSM_WIDE_PBUF;
-        } else { c.wide_g = 0; c.wide_off = -1; }
         c.perm_inv = perm_inverse((uint32_t)std::max<long>(N, 1));
         p->mask_info[4 * i] = r0; p->mask_info[4 * i + 1] = c0; p->mask_info[4 * i + 2] = c.h; p->mask_info[4 * i + 3] = c.w;
         p->mask_off_bytes[i] = c.mask_off * 4; p->xi_off[i] = c.xi_off; p->n_pixels[i] = c.N;
     }
-    p->order.resize(n);
-    std::iota(p->order.begin(), p->order.end(), 0);
-    std::stable_sort(p->order.begin(), p->order.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
-    // a candidate can only belong to a larger size class if its upper bound Mcap allows it: the larger classes get
-    // their own (shorter) launch lists instead of n workgroups that exit immediately
-    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_K1_DENSE_N || p->cand[p->order[k]].N > SDSM_WIDE_PIXELS) { p->order.push_back(p->order[k]); p->n_order_c++; }
-    for (int k = 0; k < n; k++) if (6 + p->cand[p->order[k]].Mcap > SDSM_ENV_DENSE_N) { p->order.push_back(p->order[k]); p->n_order_d++; }
-    for (int k = 0; k < n; k++) {
-        const int ci = p->order[k];
-        for (int g = 0; g < p->cand[ci].wide_g; g++) { p->order.push_back(ci | (g << 24)); p->n_order_w++; }
-    }
-    // workspace layout
-    size_t o = 0;
-    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
-    p->off_cand = take(sizeof(CandDesc) * std::max(n, 1));
-    p->off_state = take(sizeof(CandState) * std::max(n, 1));
-    p->off_fp = take(4 * std::max<size_t>(p->fp_labels.size(), 1));
-    p->off_order = take(4 * std::max<size_t>(p->order.size(), 1));
-    p->off_psf = take(4 * p->psf.size());
-    size_t np = (size_t)std::max<int64_t>(p->total_pixels, 1);
-    p->off_crop_y = take(8 * np);
-    p->off_crop_rc = take(4 * np);
-    p->off_crop_cc = take(4 * np);
-    p->off_dist = take(4 * np);
-    p->off_tmp_y = take(8 * np);
-    p->off_tmp_rc = take(4 * np);
-    p->off_inv = take(4 * np);
-    p->off_ell_meta = take(4 * np);
-    p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
-    p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
-    p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
-    p->off_env_fst = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
-    p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
-    p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1));      // n_hglob counts doubles
-    p->off_wide = take(8 * (size_t)std::max<int64_t>(p->n_wide, 1));        // n_wide counts doubles
-    p->total = o;
+    layout_plan(p);
     return p;
 }
 
@@ -248,6 +263,7 @@ extern "C" int sdsm_plan_set_latency_mode(sdsm_plan *p, int on)
 {
     if (!p) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_set_latency_mode: null plan");
     p->wide_pixels = on ? SDSM_WIDE_PIXELS : INT_MAX;
+    layout_plan(p);                                       // changes the workspace size: call before sdsm_plan_workspace_bytes
     return SDSM_OK;
 }
 extern "C" size_t sdsm_plan_workspace_bytes(const sdsm_plan *p) { return p ? p->total : 0; }
