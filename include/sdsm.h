@@ -149,9 +149,10 @@ int64_t sdsm_plan_xi_count(const sdsm_plan *plan);
 int sdsm_plan_layout(const sdsm_plan *plan, int64_t *out);
 /* Scheduling of one batch.  Throughput mode (default): every candidate whose system fits is solved by a 256-thread
  * workgroup, two per compute unit -- most candidate solves per second when several batches are in flight.  Latency mode
- * (on = 1): regions of more than 3072 pixels get a 512-thread workgroup and a compute unit of their own, which shortens
- * the slowest candidates and with them the wall clock of a single batch (the reference waits for all candidates of an
- * image before the set-cover step, globalenergymin.py:131-137).  Results do not depend on the mode. */
+ * (on = 1): regions of more than 3072 pixels are solved by a group of 2-4 cooperating 512-thread workgroups (a compute
+ * unit each), which shortens the slowest candidates and with them the wall clock of a single batch (the reference waits for all candidates of an
+ * image before the set-cover step, globalenergymin.py:131-137).  Results do not depend on the mode.  Changes the workspace size:
+ * call it right after sdsm_plan_create, before sdsm_plan_workspace_bytes. */
 int sdsm_plan_set_latency_mode(sdsm_plan *plan, int on);
 int sdsm_plan_xi_offsets(const sdsm_plan *plan, int64_t *xi_offset);
 

@@ -146,6 +146,12 @@ static uint32_t perm_inverse(uint32_t N)
     return (uint32_t)t;
 }
 
+#ifndef SDSM_LAT_SLICE
+#define SDSM_LAT_SLICE 2048         // latency mode: pixels per member of the group of a mid-size region
+#endif
+#ifndef SDSM_LAT_GMAX
+#define SDSM_LAT_GMAX 4
+#endif
 // Workgroup groups, launch lists and workspace layout (repeated when the scheduling mode changes).
 static void layout_plan(sdsm_plan *p)
 {
@@ -157,7 +163,7 @@ static void layout_plan(sdsm_plan *p)
         long G = 0;
         if (n < (1 << 24)) {
             if (c.N > SDSM_WIDE_MIN_PIXELS) G = std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (c.N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
-            else if (latency && c.N > SDSM_WIDE_PIXELS) G = std::min<long>(4, std::max<long>(2, (c.N + 2047) / 2048));   // latency mode: the largest regions of an ordinary image too
+            else if (latency && c.N > SDSM_WIDE_PIXELS) G = std::min<long>(SDSM_LAT_GMAX, std::max<long>(2, (c.N + SDSM_LAT_SLICE - 1) / SDSM_LAT_SLICE));   // latency mode: the largest regions of an ordinary image too
         }
         if (G > 0) { c.wide_g = (int32_t)G; c.wide_off = p->n_wide; p->n_wide += SDSM_WIDE_SYNC + (int64_t)2 * G * SDSM_WIDE_PBUF; }
         else { c.wide_g = 0; c.wide_off = -1; }
