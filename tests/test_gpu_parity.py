@@ -586,3 +586,33 @@ def test_random_shapes_and_hyperparameters_match_oracle(gpu, seed, sigma, subsam
         assert testing.dice(frags[k][0], frags[k][1], orecs['fg_offset'][k], ofrags[k], (H, W)) >= 0.995, k
         checked += 1
     assert checked >= 8
+
+
+def test_workgroup_group_elliptical_only_and_trivial_cases(gpu):
+    """A region of > 12288 pixels is solved by a group of workgroups; here with smooth_amount = inf (6 parameters, every
+    pass still sliced and all-reduced) and next to ordinary candidates in the same batch."""
+    from oracle import oracle
+    from superdsm_amd import engine
+    rng = np.random.default_rng(31)
+    H, W = 190, 210
+    rr, cc = np.mgrid[:H, :W]
+    y = -0.1 + 0.02 * rng.standard_normal((H, W))
+    y += 0.45 * np.exp(-(((rr - 95) / 60.0) ** 2 + ((cc - 100) / 75.0) ** 2) ** 2)
+    atoms = np.ones((H, W), np.int32)
+    atoms[:, 150:] = 2
+    for sm in (np.inf, 6.0):
+        cfg = dict(scale=1000, epsilon=1.0, alpha=0.05, smooth_amount=sm, smooth_subsample=12, gaussian_shape_multiplier=2,
+                   background_margin=10, init='elliptical')
+        fps = [[1], [2], [1, 2]]
+        img = engine.DeviceImage(y, None, atoms, cfg['background_margin'])
+        for mode in (False, True):
+            batch = engine.Batch(img, fps, cfg, latency_mode=mode)
+            batch.launch()
+            gpu.cuda.synchronize()
+            recs = batch.records()
+            orecs, _, _ = oracle.compute_objects(y, None, atoms, fps, cfg, nthreads=0)
+            assert recs['n_pixels'].max() > 12288
+            for k in range(3):
+                assert recs['status'][k] == orecs['status'][k] == 0 and recs['n_deform'][k] == orecs['M'][k]
+                tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
+                assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (sm, mode, k, recs['energy'][k], orecs['energy'][k])
