@@ -699,26 +699,17 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
     if (tid == 0) *flag = 0;
     // logical order i: xi_0 .. xi_{M-1}, theta_0 .. theta_5 (yrow, dg, zl); variable order (x, g, d): theta first
     if (M == 0) {
+        // ---- elliptical model: 6 x 6 system solved redundantly by every thread in registers (no barriers; every thread
+        //      reads the same 21 + 6 values, so non-finite input is seen by all of them alike) ----
         bool finite = true;
-        for (int i = tid; i < 6; i += L::WGS) {
-            double hii = Hp[tri(i, i)];
-            if (!(hii > 0) || !isfinite(hii)) hii = 1;
-            sc[i] = 1 / sqrt(hii);
-            if (!isfinite(g[i])) finite = false;
-        }
-        for (int e = tid; e < 21; e += L::WGS) if (!isfinite(Hp[e])) finite = false;
-        __syncthreads();
-        if (!finite) *flag = 1;
-        __syncthreads();
-        if (*flag) return 2;
-    }
-    __syncthreads();
-
-    if (M == 0) {
-        // ---- elliptical model: 6 x 6 system solved redundantly by every thread in registers (no barriers) ----
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (!isfinite(g[i])) finite = false;
+#pragma unroll
+        for (int e = 0; e < 21; e++) if (!isfinite(Hp[e])) finite = false;
+        if (!finite) return 2;
         double A[6][6], bb[6], s6[6], z[6], ri6[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) s6[i] = sc[i];
+        for (int i = 0; i < 6; i++) { double hii = Hp[tri(i, i)]; if (!(hii > 0)) hii = 1; s6[i] = rsqrt_f64(hii); }   // Jacobi scaling
         double tau = tau_in;
         bool ok = false;
         for (int attempt = 0; attempt < 12 && !ok; attempt++) {
