@@ -50,7 +50,7 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define PROF_ADD(slot, t0) do { long long _t = PROF_NOW(); prof_acc[slot] += _t - (t0); (t0) = _t; } while (0)
 #else
 #define PROF_NOW() 0ll
-#define PROF_ADD(slot, t0) do { } while (0)
+#define PROF_ADD(slot, t0) do { (void)(t0); } while (0)
 #endif
 
 enum { ST_OK = 0, ST_TRIVIAL = 2, ST_ERROR = 3, ST_UNSUPPORTED = 4 };

@@ -693,7 +693,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
     long long pf = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M;
-    double *Hp = hess_ptr<L>(c), *g = SD + L::G, *sc = SD + L::SC, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *zl = SD + L::XT;   // XT is free between line searches
+    double *Hp = hess_ptr<L>(c), *g = SD + L::G, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *zl = SD + L::XT;   // XT is free between line searches
     const int *rbp = RBP, *fstp = FSTP, *rendp = RENDP;
     int *flag = (int *)(SD + L::FLAG);
     if (tid == 0) *flag = 0;
