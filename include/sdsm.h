@@ -156,6 +156,17 @@ int sdsm_plan_layout(const sdsm_plan *plan, int64_t *out);
 int sdsm_plan_set_latency_mode(sdsm_plan *plan, int on);
 int sdsm_plan_xi_offsets(const sdsm_plan *plan, int64_t *xi_offset);
 
+/* Parity / debug: psi, its gradient and the polynomial (theta) block of its Hessian at caller-given parameters, computed
+ * by the evaluators of the solve kernels (Energy.__call__ / grad / hessian, superdsm/dsm.py:312-385) on the crops and G~
+ * rows that a previous sdsm_batch_launch of the same plan left in the workspace.  d_params: sdsm_plan_eval_param_count()
+ * doubles, candidate i's vector (theta[6] in full-image-normalised coordinates, then xi[M]) at 6 * i + xi_offset[i].
+ * d_out: sdsm_plan_eval_out_count() doubles: [2 i], [2 i + 1] psi by the full and by the value-only evaluator;
+ * [2 n + 21 i ..] lower triangle (row-major) of the 6x6 theta block of the Hessian; [23 n + 6 i + xi_offset[i] ..] the
+ * gradient in the layout of d_params.  Candidates without a solve (trivial, failed, beyond the limits) get NaN. */
+int64_t sdsm_plan_eval_param_count(const sdsm_plan *plan);
+int64_t sdsm_plan_eval_out_count(const sdsm_plan *plan);
+int sdsm_batch_eval(const sdsm_plan *plan, void *d_workspace, size_t workspace_bytes, const double *d_params, double *d_out, void *stream);
+
 /* Timing of the dominant kernel with HIP events on the launch stream: after sdsm_batch_launch returns,
  * sdsm_last_solve_kernel_ms() synchronises on the recorded events and returns the solve kernels' duration. */
 int sdsm_enable_kernel_timing(int enable);

@@ -22,13 +22,14 @@ def build(force=False):
 
 class DsmCfg(C.Structure):
     _fields_ = [('scale', C.c_double), ('epsilon', C.c_double), ('alpha', C.c_double), ('smooth_amount', C.c_double),
-                ('gaussian_shape_multiplier', C.c_double), ('smooth_subsample', C.c_int), ('init_elliptical', C.c_int)]
+                ('gaussian_shape_multiplier', C.c_double), ('smooth_subsample', C.c_int), ('init_elliptical', C.c_int),
+                ('max_iters', C.c_int), ('pad', C.c_int)]
 
     @staticmethod
     def from_dict(d):
         return DsmCfg(float(d.get('scale', 1000)), float(d.get('epsilon', 1.0)), float(d.get('alpha', 0.5)),
                       float(d.get('smooth_amount', 10)), float(d.get('gaussian_shape_multiplier', 2)),
-                      int(d.get('smooth_subsample', 20)), int(d.get('init', 'elliptical') == 'elliptical'))
+                      int(d.get('smooth_subsample', 20)), int(d.get('init', 'elliptical') == 'elliptical'), int(d.get('max_iters', 100)), 0)
 
 
 class CvxprogInfo(C.Structure):

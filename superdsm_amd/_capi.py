@@ -57,6 +57,9 @@ SYMBOLS = {
     'sdsm_plan_xi_offsets': (_i32, [_vp, _vp]),
     'sdsm_plan_layout': (_i32, [_vp, _vp]),
     'sdsm_plan_set_latency_mode': (_i32, [_vp, _i32]),
+    'sdsm_plan_eval_param_count': (_i64, [_vp]),
+    'sdsm_plan_eval_out_count': (_i64, [_vp]),
+    'sdsm_batch_eval': (_i32, [_vp, _vp, _sz, _vp, _vp, _vp]),
     'sdsm_enable_kernel_timing': (_i32, [_i32]),
     'sdsm_last_solve_kernel_ms': (_f64, []),
     'sdsm_last_setup_kernel_ms': (_f64, []),

@@ -322,6 +322,33 @@ static thread_local long long *g_prof = nullptr;
 // Diagnostic builds (-DSDSM_PROFILE): device buffer of 8 int64 cycle counters per candidate, see DESIGN.md.
 extern "C" int sdsm_set_debug_buffer(void *d_buf) { g_prof = (long long *)d_buf; return SDSM_OK; }
 
+
+#ifndef SDSM_HESS_THR
+#define SDSM_HESS_THR 0.1f    // same constant as the oracle's ORC_HESS_THR
+#endif
+// Kernel arguments of a plan laid out in the caller's workspace.
+static BatchParams make_params(const sdsm_plan *p, void *d_ws)
+{
+    uint8_t *b = (uint8_t *)d_ws;
+    BatchParams P{};
+    P.n = p->n; P.H = p->H; P.W = p->W; P.n_atoms = p->n_atoms;
+    P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
+    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels;
+    P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
+    P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);
+    P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);
+    P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);
+    P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
+    P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_meta = (uint32_t *)(b + p->off_ell_meta);
+    P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc); P.inv = (uint32_t *)(b + p->off_inv);
+    P.hess_thr = SDSM_HESS_THR;
+    P.psf = (const float *)(b + p->off_psf);
+    P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
+    P.hglob = (double *)(b + p->off_hglob); P.wide_pool = (double *)(b + p->off_wide);
+    P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
+    return P;
+}
+
 // side streams / fork-join events of the three solve classes: one set per caller stream (created on first use, per
 // host thread), so that batches queued on different streams overlap instead of serialising on shared side streams
 struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; };
@@ -357,27 +384,8 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     if (!p || !d_y || !d_atoms || !d_valid || !d_ws || !d_records || !d_masks) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: null argument");
     if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_launch: workspace too small");
     if (p->n == 0) return SDSM_OK;
-    uint8_t *b = (uint8_t *)d_ws;
     hipStream_t s = (hipStream_t)stream;
-    BatchParams P{};
-    P.n = p->n; P.H = p->H; P.W = p->W; P.n_atoms = p->n_atoms;
-    P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
-    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels;
-    P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
-    P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);
-    P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);
-    P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);
-    P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
-    P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_meta = (uint32_t *)(b + p->off_ell_meta);
-    P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc); P.inv = (uint32_t *)(b + p->off_inv);
-#ifndef SDSM_HESS_THR
-#define SDSM_HESS_THR 0.1f    // same constant as the oracle's ORC_HESS_THR
-#endif
-    P.hess_thr = SDSM_HESS_THR;
-    P.psf = (const float *)(b + p->off_psf);
-    P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
-    P.hglob = (double *)(b + p->off_hglob); P.wide_pool = (double *)(b + p->off_wide);
-    P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
+    const BatchParams P = make_params(p, d_ws);
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     if ((e = sdsm_launch_setup(P, (const double *)d_y, (const int32_t *)d_atoms, (const uint8_t *)d_valid, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch setup");
@@ -393,5 +401,25 @@ extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const in
     }
     if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], ss->side[2], ss->fj, p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
+    return SDSM_OK;
+}
+
+// ---- point evaluation for parity tests ---------------------------------------------------------------------
+extern "C" hipError_t sdsm_launch_eval(const BatchParams &P, const double *params, double *out, hipStream_t stream);
+
+extern "C" int64_t sdsm_plan_eval_param_count(const sdsm_plan *p) { return p ? (int64_t)6 * p->n + std::max<int64_t>(p->total_xi, 1) : 0; }
+extern "C" int64_t sdsm_plan_eval_out_count(const sdsm_plan *p) { return p ? (int64_t)29 * p->n + std::max<int64_t>(p->total_xi, 1) : 0; }
+
+extern "C" int sdsm_batch_eval(const sdsm_plan *p, void *d_ws, size_t ws_bytes, const double *d_params, double *d_out, void *stream)
+{
+    if (!p || !d_ws || !d_params || !d_out) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_eval: null argument");
+    if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_eval: workspace too small");
+    if (p->n == 0) return SDSM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    // results of candidates that cannot be evaluated (trivial, failed setup, beyond the solver's limits) stay NaN
+    if ((e = hipMemsetAsync(d_out, 0xff, sizeof(double) * (size_t)sdsm_plan_eval_out_count(p), s)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
+    const BatchParams P = make_params(p, d_ws);
+    if ((e = sdsm_launch_eval(P, d_params, d_out, s)) != hipSuccess) return hipfail(e, "launch eval");
     return SDSM_OK;
 }

@@ -334,11 +334,8 @@ __device__ __forceinline__ double smooth_term(const Cand &c, const double *xv, i
 
 // psi only (line search, final energy).  Result broadcast to all threads.
 template <class L>
-__device__ __noinline__ double eval_value(const Cand &c_in, int xo_in, int M_in)
+__device__ __forceinline__ double eval_value(const Cand &c, int xo, int M)
 {
-    const Cand c = uniform_cand(c_in);
-    const int xo = uni(xo_in);
-    const int M = uni(M_in);
     const double *xv = SD + xo;
     double psi = 0;
     for (int p = c.p_lo + threadIdx.x; p < c.p_hi; p += L::WGS) {
@@ -366,18 +363,15 @@ __device__ __noinline__ double eval_value(const Cand &c_in, int xo_in, int M_in)
         double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
         psi += o2 < 0 ? 0 : o2;
     }
-    return psi;
+    return uni(psi);                                     // every thread holds the same sum: scalar from here on (uniform control flow in the solver)
 }
 
 // Line search sweep: psi(x + t_k d) for LS_K step lengths t_k = t0 * 2^-k in ONE pass over the pixels.  S is linear in
 // the parameters, S(x + t d) = S(x) + t S(d): the row of G~ is fetched once, applied to xi and to d_xi (interleaved pairs
 // (x_j, d_j) at L::XT .. so one 16-byte LDS read serves both), and only the loss is evaluated LS_K times.
 template <class L>
-__device__ __noinline__ void eval_line(const Cand &c_in, int M_in, double t0_in, double (&out)[LS_K])
+__device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, double (&out)[LS_K])
 {
-    const Cand c = uniform_cand(c_in);
-    const int M = uni(M_in);
-    const double t0 = uni(t0_in);
     const int tid = threadIdx.x, n = 6 + M;
     const double *x = SD + L::X, *d = SD + L::D;
     double *xd = SD + L::XT;
@@ -460,13 +454,15 @@ __device__ __noinline__ void eval_line(const Cand &c_in, int M_in, double t0_in,
         for (int k = 0; k < LS_K; k++) { const double o2 = c.alpha * rs[k] - c.alpha * sqrt(c.epsilon) * M; ps[k] += o2 < 0 ? 0 : o2; }
     }
 #pragma unroll
-    for (int k = 0; k < LS_K; k++) out[k] = ps[k];
+    for (int k = 0; k < LS_K; k++) out[k] = uni(ps[k]);
     __syncthreads();
 }
 
-// regulariser contributions to psi, gradient and Hessian diagonal (dsm.py:323-331, 349, 372-376)
+// regulariser contributions to psi, gradient and Hessian diagonal (dsm.py:323-331, 349, 372-376).  reg_mu in [0, 1] blends the
+// curvature from its true value alpha eps / (xi^2 + eps)^(3/2) towards alpha / sqrt(xi^2 + eps), the curvature of the
+// quadratic majoriser of alpha sqrt(xi^2 + eps) (solver approximation only, DESIGN.md "Solver"; psi and the gradient are exact)
 template <class L>
-__device__ __forceinline__ double add_regulariser(const Cand &c, int M)
+__device__ __forceinline__ double add_regulariser(const Cand &c, int M, double reg_mu)
 {
     const double *xv = SD + L::X;
     double *g = SD + L::G, *Hp = hess_ptr<L>(c);
@@ -476,7 +472,9 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M)
         s2 += t2;
         g[6 + j] += c.alpha * (xi / t2);
         double gd = c.alpha * (1 / t2 - t3 / (t2 * t2 * t2));
-        Hp[RBP[j] + j] += gd < 0 ? 0 : gd;
+        gd = gd < 0 ? 0 : gd;
+        gd += reg_mu * (c.alpha / t2 - gd);
+        Hp[RBP[j] + j] += gd;
     }
     s2 = block_sum<L::NWAVES>(s2, SD + L::RED);
     double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
@@ -488,9 +486,8 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M)
 // per-lane register sums over the lane's pixels, reduced with wavefront shuffles + one LDS hop.
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ double eval_full_ell(const Cand &c_in PROF_PARAM)
+__device__ __forceinline__ double eval_full_ell(const Cand &c PROF_PARAM)
 {
-    const Cand c = uniform_cand(c_in);
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
     double *Hp = hess_ptr<L>(c), *g = SD + L::G;
@@ -529,17 +526,15 @@ __device__ __noinline__ double eval_full_ell(const Cand &c_in PROF_PARAM)
         __syncthreads();
     }
     PROF_ADD(2, pt);
-    return psi;
+    return uni(psi);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // SPARSE full evaluation (n > 40): per-pixel products added into the packed Hessian in LDS (ds_add_f64).
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M_in PROF_PARAM)
+__device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double reg_mu PROF_PARAM)
 {
-    const Cand c = uniform_cand(c_in);
-    const int M = uni(M_in);
     long long pt = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M;
@@ -660,10 +655,10 @@ __device__ __noinline__ double eval_full_sparse(const Cand &c_in, int M_in PROF_
         psi = tmp[0];
         __syncthreads();
     }
-    if (M > 0) psi += add_regulariser<L>(c, M);
+    if (M > 0) psi += add_regulariser<L>(c, M, reg_mu);
     __syncthreads();
     PROF_ADD(2, pt);
-    return psi;
+    return uni(psi);
 }
 
 // 1 / sqrt(x), x in the normal range: hardware estimate (5.2e-8 relative) + ONE Newton step = 4.2e-15 relative (37 ulp,
@@ -685,11 +680,8 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 // 2 non-finite input.  *lam2 = -g.d.
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_in_in, double *lam2 PROF_PARAM)
+__device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in, double *lam2 PROF_PARAM)
 {
-    const Cand c = uniform_cand(c_in);
-    const int M = uni(M_in);
-    const double tau_in = uni(tau_in_in);
     long long pf = PROF_NOW();
     const int tid = threadIdx.x;
     const int n = 6 + M;
@@ -706,7 +698,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
         for (int i = 0; i < 6; i++) if (!isfinite(g[i])) finite = false;
 #pragma unroll
         for (int e = 0; e < 21; e++) if (!isfinite(Hp[e])) finite = false;
-        if (!finite) return 2;
+        if (uni((int)!finite)) return 2;                        // (every thread read the same values)
         double A[6][6], bb[6], s6[6], z[6], ri6[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) { double hii = Hp[tri(i, i)]; if (!(hii > 0)) hii = 1; s6[i] = rsqrt_f64(hii); }   // Jacobi scaling
@@ -743,7 +735,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
             }
             if (!ok) tau = tau == 0 ? 1e-12 : tau * 100;
         }
-        if (!ok) return 2;
+        if (uni((int)!ok)) return 2;
         double l2 = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) l2 += z[i] * z[i];
@@ -757,10 +749,10 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
         bool fin = isfinite(l2);
 #pragma unroll
         for (int i = 0; i < 6; i++) { z[i] *= s6[i]; if (!isfinite(z[i])) fin = false; }
-        if (!fin) return 2;                                       // uniform: every thread computed the same values
+        if (uni((int)!fin)) return 2;                             // uniform: every thread computed the same values
         if (tid < 6) d[tid] = z[tid];
         __syncthreads();
-        *lam2 = l2;
+        *lam2 = uni(l2);
         return 0;
     }
 
@@ -859,7 +851,7 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
         PROF_ADD(9, pf);
         __syncthreads();
         PROF_ADD(10, pf);
-        failed = pflag[(j0 >> NBSH) & 1];                         // uniform (two slots: a thread is at most one panel ahead)
+        failed = uni(pflag[(j0 >> NBSH) & 1]);                    // uniform (two slots: a thread is at most one panel ahead)
         if (failed) break;
         // C. factored block, reciprocal diagonal and solved panel entries (columns j0 .. j0+3: not read again before
         //    the back substitution, so the next panel starts without another barrier)
@@ -944,60 +936,100 @@ __device__ __noinline__ int factor_solve(const Cand &c_in, int M_in, double tau_
     if (!fin) *flag = 1;
     __syncthreads();
     PROF_ADD(15, pf);
-    if (*flag) return 2;
-    *lam2 = l2;
+    if (uni(*flag)) return 2;
+    *lam2 = uni(l2);
     return 0;
 }
 
-// Damped Newton on f = scale * psi from the parameters at L::X (in/out).
-// Returns 0 optimal, 1 unknown (iteration cap / stalled line search), 2 numerical failure.
+// Damped Newton on f = scale * psi from the parameters at L::X (in/out); the same algorithm and constants as the oracle's
+// orc_newton (DESIGN.md "Solver").  Returns 0 optimal, 1 unknown (iteration cap / stalled line search), 2 numerical failure.
+// Written as a state machine around ONE call site of every pass (full evaluation, factorisation, line-search sweep, value):
+// everything is inlined into the kernel once, nothing lives on the stack.  `why` says what the next full evaluation is for:
+//   EV_STEP   a new iterate (start, accepted line-search step)
+//   EV_SPEC   speculative full step x + d (previous accepted step length was 1, or first iteration of a DSM solve): if it
+//             meets the Armijo condition the iteration is done without a line-search pass, otherwise x is restored and the
+//             sweeps start at t = 1/2
+//   EV_RETRY  the factorisation hit a non-positive pivot and destroyed the Hessian: evaluate again, larger diagonal shift
+//   EV_CHECK  the stop test passed with mu > 0 (inflated regulariser curvature underestimates the Newton decrement):
+//             evaluate again with the true curvature
+#define MU_DECAY 0.5
+#define MU_MIN 1e-3
 template <class L>
 __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, double *psi_out, int *iters_out, int *ev_value, int *ev_full PROF_PARAM)
 {
+    enum { EV_STEP = 0, EV_SPEC = 1, EV_RETRY = 2, EV_CHECK = 3 };
     const int tid = threadIdx.x, n = 6 + M;
-    double *x = SD + L::X, *xt = SD + L::XT, *d = SD + L::D;
-    int status = 1, iters = 0;
+    double *x = SD + L::X, *xt = SD + L::XT, *d = SD + L::D, *xb = SD + L::YROW;   // YROW is only live inside factor_solve
+    int status = 1, iters = 0, why = EV_STEP, retries = 0;
+    double mu = M > 0 ? 1.0 : 0.0, mu_spec = 0, tprev = 0, tau = 0;
+    double psi = NAN, f = NAN, lam2 = 0;                     // f, lam2 describe x (kept across a speculative evaluation)
     for (;;) {
-        double psi;
-        if (M == 0) psi = eval_full_ell<L>(c PROF_ARG);
-        else psi = eval_full_sparse<L>(c, M PROF_ARG);
+        double pe;
+        if (M == 0) pe = eval_full_ell<L>(c PROF_ARG);
+        else pe = eval_full_sparse<L>(c, M, why == EV_SPEC ? mu_spec : mu PROF_ARG);
         (*ev_full)++;
         long long pt = PROF_NOW();
-        double f = c.scale * psi;
-        if (iters >= max_iters) { status = 1; break; }
-        if (!isfinite(f)) { status = 2; break; }
-        double lam2u, tau = 0;
-        int fs = factor_solve<L>(c, M, tau, &lam2u PROF_ARG);
-        for (int attempt = 1; fs == 1 && attempt < 12; attempt++) {      // escalating diagonal shift (same schedule as the oracle)
-            tau = tau == 0 ? 1e-12 : tau * 100;
-            eval_full_sparse<L>(c, M PROF_ARG);                            // the failed factorisation overwrote the Hessian
-            fs = factor_solve<L>(c, M, tau, &lam2u PROF_ARG);
-        }
-        if (fs != 0) { status = 2; break; }
-        double lam2 = c.scale * lam2u;
-        iters++;
-        PROF_ADD(3, pt);
-        if (lam2 * 0.5 <= NEWTON_ABSTOL + NEWTON_RELTOL * fabs(f)) {
-            // converged: final full step, kept only if it does not increase f (near-separable regions have a
-            // vanishing Hessian and the unguarded step can be arbitrarily bad)
-            for (int i = tid; i < n; i += L::WGS) xt[i] = x[i] + d[i];
-            __syncthreads();
-            const double psit = eval_value<L>(c, L::XT, M);
-            (*ev_value)++;
-            if (isfinite(psit) && c.scale * psit <= f) {
-                for (int i = tid; i < n; i += L::WGS) x[i] = xt[i];
+        bool line = false;
+        double t0 = M == 0 ? LS_T0_ELL : 1.0;
+        if (why == EV_SPEC) {
+            if (isfinite(pe) && c.scale * pe <= f - LS_ALPHA * lam2) { psi = pe; tprev = 1.0; mu = mu_spec; why = EV_STEP; }
+            else {                                           // back to x; t = 1 is known to fail
                 __syncthreads();
-                *psi_out = psit;
-                *iters_out = iters;
-                return 0;
+                for (int i = tid; i < n; i += L::WGS) x[i] = xb[i];
+                __syncthreads();
+                line = true; t0 = 0.5;
             }
-            status = 0;
-            break;
+        } else if (why != EV_RETRY) psi = pe;
+        if (!line) {
+            if (why != EV_RETRY) {
+                if (iters >= max_iters) { status = 1; break; }
+                f = c.scale * psi;
+                if (!isfinite(f)) { status = 2; break; }
+                tau = 0; retries = 0;
+            }
+            double lam2u;
+            const int fs = factor_solve<L>(c, M, tau, &lam2u PROF_ARG);
+            if (fs == 1 && retries < 11) {                   // escalating diagonal shift (same schedule as the oracle)
+                retries++;
+                tau = tau == 0 ? 1e-12 : tau * 100;
+                why = EV_RETRY;
+                continue;
+            }
+            if (fs != 0) { status = 2; break; }
+            lam2 = c.scale * lam2u;
+            PROF_ADD(3, pt);
+            const bool conv = lam2 * 0.5 <= NEWTON_ABSTOL + NEWTON_RELTOL * fabs(f);
+            if (conv && mu > 0) { mu = 0; why = EV_CHECK; continue; }
+            iters++;
+            if (conv) {
+                // converged: final full step, kept only if it does not increase f (near-separable regions have a
+                // vanishing Hessian and the unguarded step can be arbitrarily bad)
+                for (int i = tid; i < n; i += L::WGS) xt[i] = x[i] + d[i];
+                __syncthreads();
+                const double psit = eval_value<L>(c, L::XT, M);
+                (*ev_value)++;
+                if (isfinite(psit) && c.scale * psit <= f) {
+                    for (int i = tid; i < n; i += L::WGS) x[i] = xt[i];
+                    __syncthreads();
+                    psi = psit;
+                }
+                status = 0;
+                break;
+            }
+            if (tprev == 1.0 || (iters == 1 && M > 0)) {
+                mu_spec = mu * MU_DECAY;
+                mu_spec = mu_spec < MU_MIN ? 0 : mu_spec;
+                __syncthreads();
+                for (int i = tid; i < n; i += L::WGS) { const double xi = x[i]; xb[i] = xi; x[i] = xi + d[i]; }
+                __syncthreads();
+                why = EV_SPEC;
+                continue;
+            }
         }
         // line search: sweeps of LS_K step lengths evaluated together; the accepted step is the one with the smallest f
         // among those that satisfy the Armijo condition (same rule as the oracle)
         bool accepted = false;
-        double tbest = 0, fbest = INFINITY, t0 = M == 0 ? LS_T0_ELL : 1.0;
+        double tbest = 0, fbest = INFINITY;
         for (int sweep = 0; sweep < LS_SWEEPS && !accepted; sweep++) {
             double fs[LS_K];
             eval_line<L>(c, M, t0, fs);
@@ -1012,12 +1044,17 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
             t0 = tk;
         }
         PROF_ADD(4, pt);
-        if (!accepted) { status = 1; break; }
+        if (!accepted) { status = 1; break; }               // stalled; psi still is the value at x
         for (int i = tid; i < n; i += L::WGS) x[i] += tbest * d[i];
         __syncthreads();
+        tprev = tbest;
+        if (M > 0) {
+            if (tbest >= 1) { mu *= MU_DECAY; mu = mu < MU_MIN ? 0 : mu; }
+            else mu = 1.0;
+        }
+        why = EV_STEP;
     }
-    *psi_out = eval_value<L>(c, L::X, M);
-    (*ev_value)++;
+    *psi_out = psi;
     *iters_out = iters;
     return status;
 }
@@ -1109,6 +1146,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     const double z0 = P.H > 1 ? P.H - 1.0 : 1.0, z1 = P.W > 1 ? P.W - 1.0 : 1.0;
     const double P0 = 1.0 / (c.inv_hr * z0), P1 = 1.0 / (c.inv_hc * z1), O0 = c.rmid / z0, O1 = c.cmid / z1;
     double *x = SD + L::X, *xt = SD + L::XT;
+    c = uniform_cand(c);                                        // per-candidate scalars and pointers into SGPRs (they are computed by vector instructions)
 
 #ifdef SDSM_PROFILE
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1180,28 +1218,28 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 #endif
         if (phase < 2) {
             r.iters_ell += its;
-            if (s != 2) { have = true; psi_ell = psi; for (int i = 0; i < 6; i++) keep[i] = x[i]; s_prev = s; }
+            if (s != 2) { have = true; psi_ell = psi; for (int i = 0; i < 6; i++) keep[i] = uni(x[i]); s_prev = s; }
             else if (phase == 0) s_prev = 2;
             __syncthreads();
         } else {
             r.iters_dsm = its;
             psi_final = psi;
-            if (s == 2) fallback = true;                                        // exception -> fallback
-            else if (s == 1) {                                                  // 'unknown' and worse than the start
+            if (s != 0) {
+                // exception -> fallback; 'unknown' and worse than the start -> fallback (objects.py:399-410).  The start's energy
+                // comes from the value-only evaluator, psi from the full one: the same sums in a different reduction order, so
+                // "worse" allows for rounding (same rule in the oracle)
                 __syncthreads();
                 for (int i = tid; i < NMAX; i += L::WGS) xt[i] = i < 6 ? keep[i] : 0;
                 __syncthreads();
-                double vi = eval_value<L>(c, L::XT, Mfull);
+                const double vi = eval_value<L>(c, L::XT, Mfull);
                 ev_value++;
-                if (psi > vi) fallback = true;
-            }
-            if (fallback) {
-                __syncthreads();
-                for (int i = tid; i < NMAX; i += L::WGS) x[i] = i < 6 ? keep[i] : 0;
-                __syncthreads();
-                psi_final = eval_value<L>(c, L::X, Mfull);
-                ev_value++;
-                status_final = SDSM_CAND_FALLBACK;
+                if (s == 2 || psi > vi * (1 + 1e-12)) {
+                    fallback = true;
+                    for (int i = tid; i < NMAX; i += L::WGS) x[i] = xt[i];
+                    __syncthreads();
+                    psi_final = vi;
+                    status_final = SDSM_CAND_FALLBACK;
+                }
             }
         }
     }
@@ -1279,6 +1317,124 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         if (rmax >= 0) { r.fg_r0 = rmin; r.fg_c0 = cmin; r.fg_h = rmax - rmin + 1; r.fg_w = cmax - cmin + 1; }
         *rec = r;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Point evaluation for parity tests (sdsm_batch_eval): psi, gradient and the polynomial block of the Hessian at
+// caller-given parameters, computed by the SAME evaluators the solver uses (eval_full_ell / eval_full_sparse: loss_terms;
+// eval_value: softplus_neg) on the crops and G~ rows a previous sdsm_batch_launch left in the workspace.  Parameters and
+// results are in the reference's full-image-normalised basis (dsm.py:49-54); the evaluators work in the candidate's local
+// basis theta_local = R theta (reparam), so grad = R^T grad_local and H = R^T H_local R.
+// out: [0, 2n) psi by the full and by the value-only evaluator; [2n, 23n) lower triangle of the 6x6 polynomial Hessian
+// block; [23n, ...) gradients in the layout of `params`: candidate i at 6 i + xi_off(i), theta then xi.
+// ---------------------------------------------------------------------------------------------------------
+template <int NMAX, int EMAX, bool GLOBALH, int WGSIZE>
+__global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, int eprev, const double *params, double *out)
+{
+    using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
+    const int tid = threadIdx.x;
+    const int ci = blockIdx.x;
+    const CandDesc cd = P.cand[ci];
+    const CandState st = P.state[ci];
+    if (st.status != ST_OK || st.M < 0 || 6 + st.M > SDSM_MAX_N_SOLVE) return;            // out stays NaN (filled by the host)
+    const int M = st.M, n = 6 + M;
+    const int efull = M > 0 ? st.env_size : 21;
+    if (nprev > 0 && n <= nprev && efull <= eprev) return;                                 // an earlier class evaluates it
+    if (!(n <= NMAX && efull <= EMAX)) return;
+    if (GLOBALH && cd.hglob_off < 0) return;
+    Cand c;
+    c.N = cd.N; c.zmax = M > 0 ? st.zmax : 0; c.hzmax = M > 0 ? st.hzmax : 0; c.env_size = efull;
+    c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr;
+    c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
+    c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
+#pragma unroll
+    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = M > 0 ? st.gcount[j] : 0;
+    c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
+    c.scale = P.scale / cd.N; c.epsilon = P.epsilon; c.alpha = P.alpha;
+    const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
+    c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
+    c.inv_hr = 1.0 / (half_r < 1 ? 1 : half_r); c.inv_hc = 1.0 / (half_c < 1 ? 1 : half_c);
+    const double z0 = P.H > 1 ? P.H - 1.0 : 1.0, z1 = P.W > 1 ? P.W - 1.0 : 1.0;
+    const double P0 = 1.0 / (c.inv_hr * z0), P1 = 1.0 / (c.inv_hc * z1), O0 = c.rmid / z0, O1 = c.cmid / z1;
+    c = uniform_cand(c);
+    double *x = SD + L::X, *g = SD + L::G, *Hp = hess_ptr<L>(c);
+    const double *pin = params + (size_t)6 * ci + cd.xi_off;
+    if (tid == 0) {
+        *WIDE_PHASE = 0;
+        double thg[6], thl[6];
+        for (int i = 0; i < 6; i++) thg[i] = pin[i];
+        reparam(thg, P0, P1, O0, O1, thl);
+        for (int i = 0; i < 6; i++) x[i] = thl[i];
+    }
+    for (int j = tid; j < M; j += L::WGS) x[6 + j] = pin[6 + j];
+    if (M > 0) {
+        int *rbp = RBP, *fstp = FSTP, *rendp = RENDP;
+        const int exi = efull - 6 * M - 21;
+        for (int a = tid; a < M; a += L::WGS) { rbp[a] = P.env_rb[cd.xi_off + a]; fstp[a] = P.env_fst[cd.xi_off + a]; }
+        if (tid < 6) { rbp[M + tid] = exi + tid * M + tid * (tid + 1) / 2; fstp[M + tid] = 0; }
+        if (tid == 0) rendp[0] = M - 1;
+    }
+    __syncthreads();
+#ifdef SDSM_PROFILE
+    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const double psi_value = eval_value<L>(c, L::X, M);
+    const double psi_full = M == 0 ? eval_full_ell<L>(c PROF_ARG) : eval_full_sparse<L>(c, M, 0.0 PROF_ARG);
+    __syncthreads();
+    if (tid == 0) {
+        double Rm[6][6];                                   // theta_local = Rm theta_global (reparam is linear in theta)
+        for (int a = 0; a < 6; a++) {
+            double e[6] = {0, 0, 0, 0, 0, 0}, col[6];
+            e[a] = 1;
+            reparam(e, P0, P1, O0, O1, col);
+            for (int b = 0; b < 6; b++) Rm[b][a] = col[b];
+        }
+        double Hl[6][6];
+        for (int a = 0; a < 6; a++) for (int b = 0; b <= a; b++) {
+            const double v = M == 0 ? Hp[tri(a, b)] : Hp[RBP[M + a] + M + b];
+            Hl[a][b] = v; Hl[b][a] = v;
+        }
+        out[2 * ci] = psi_full; out[2 * ci + 1] = psi_value;
+        double *oh = out + (size_t)2 * P.n + (size_t)21 * ci;
+        for (int a = 0; a < 6; a++) for (int b = 0; b <= a; b++) {
+            double v = 0;
+            for (int k = 0; k < 6; k++) for (int l = 0; l < 6; l++) v += Rm[k][a] * Hl[k][l] * Rm[l][b];
+            oh[tri(a, b)] = v;
+        }
+        double *og = out + (size_t)23 * P.n + (size_t)6 * ci + cd.xi_off;
+        for (int a = 0; a < 6; a++) {
+            double v = 0;
+            for (int k = 0; k < 6; k++) v += Rm[k][a] * g[k];
+            og[a] = v;
+        }
+    }
+    double *og = out + (size_t)23 * P.n + (size_t)6 * ci + cd.xi_off;
+    for (int j = tid; j < M; j += L::WGS) og[6 + j] = g[6 + j];
+}
+
+extern "C" hipError_t sdsm_launch_eval(const BatchParams &P, const double *params, double *out, hipStream_t stream)
+{
+    if (P.n <= 0) return hipSuccess;
+    hipError_t e;
+    {
+        auto kern = sdsm_k_eval<SDSM_K1_NMAX, SDSM_K1_EMAX, false, 256>;
+        constexpr int lds = Lay<SDSM_K1_NMAX, SDSM_K1_EMAX, false, 256>::TOTAL_BYTES;
+        if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(P.n), dim3(256), lds, stream, P, 0, 0, params, out);
+    }
+    {
+        auto kern = sdsm_k_eval<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, false, 512>;
+        constexpr int lds = Lay<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, false, 512>::TOTAL_BYTES;
+        if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(P.n), dim3(512), lds, stream, P, SDSM_K1_NMAX, SDSM_K1_EMAX, params, out);
+    }
+    {
+        auto kern = sdsm_k_eval<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, true, 512>;
+        constexpr int lds = Lay<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, true, 512>::TOTAL_BYTES;
+        if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(P.n), dim3(512), lds, stream, P, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, params, out);
+    }
+    return hipGetLastError();
 }
 
 // ---- launch helper (called from sdsm_api.hip) ----------------------------------------------------

@@ -128,6 +128,32 @@ class Batch:
         _capi.check(_capi.lib().sdsm_plan_xi_offsets(self.plan, off.ctypes.data_as(C.c_void_p)), 'sdsm_plan_xi_offsets')
         return off
 
+    def evaluate(self, params):
+        """Point evaluation for parity tests (sdsm_batch_eval): ``params[i]`` = theta (6, full-image-normalised) + xi (M) of
+        candidate i.  Needs a previous :meth:`launch`.  Returns a list of dicts: psi (full evaluator), psi_value
+        (value-only evaluator), grad (6 + M), hess_theta (6 x 6, symmetric)."""
+        L = _capi.lib()
+        xo = self.xi_offsets()
+        buf = np.zeros(L.sdsm_plan_eval_param_count(self.plan))
+        for i, p in enumerate(params):
+            p = np.asarray(p, np.float64)
+            buf[6 * i + xo[i]:6 * i + xo[i] + p.size] = p
+        dev = self.image.device
+        d_par = torch.from_numpy(buf).to(dev)
+        d_out = torch.empty(L.sdsm_plan_eval_out_count(self.plan), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _capi.check(L.sdsm_batch_eval(self.plan, _ptr(self.ws), self.ws_bytes, _ptr(d_par), _ptr(d_out), _stream()), 'sdsm_batch_eval')
+        out = d_out.cpu().numpy()
+        res = []
+        for i, p in enumerate(params):
+            m = len(p)
+            H = np.zeros((6, 6))
+            H[np.tril_indices(6)] = out[2 * self.n + 21 * i:2 * self.n + 21 * i + 21]
+            H = H + np.tril(H, -1).T
+            g0 = 23 * self.n + 6 * i + xo[i]
+            res.append(dict(psi=float(out[2 * i]), psi_value=float(out[2 * i + 1]), grad=out[g0:g0 + m].copy(), hess_theta=H))
+        return res
+
     def inspect(self):
         """Setup-phase outputs for parity tests: per candidate (N, M, status, pixel coordinates, grid points,
         CSR-like G~ rows).  Reads the workspace back to the host."""

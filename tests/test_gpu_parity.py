@@ -202,7 +202,7 @@ def test_full_size_properties_bbbc039_like(gpu):
     res = testing.solve_scene_gpu(scene)
     recs = res['records']
     ok = recs['status'] == _capi.CAND_OPTIMAL
-    assert ok.mean() > 0.95
+    assert ok.all(), np.unique(recs['status'], return_counts=True)
     assert np.isfinite(recs['energy'][ok]).all() and (recs['energy'][ok] >= 0).all()
     # the DSM can only improve on the elliptical model it starts from (monotone line search)
     assert (recs['energy'][ok] <= recs['energy_ell'][ok] * (1 + 1e-9) + 1e-9).all()
@@ -583,7 +583,7 @@ def test_random_shapes_and_hyperparameters_match_oracle(gpu, seed, sigma, subsam
             continue
         tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
         assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (k, recs['energy'][k], orecs['energy'][k])
-        assert testing.dice(frags[k][0], frags[k][1], orecs['fg_offset'][k], ofrags[k], (H, W)) >= 0.995, k
+        assert testing.dice(frags[k][0], frags[k][1], orecs['fg_offset'][k], ofrags[k], (H, W)) >= 0.999, k
         checked += 1
     assert checked >= 8
 
@@ -616,3 +616,252 @@ def test_workgroup_group_elliptical_only_and_trivial_cases(gpu):
                 assert recs['status'][k] == orecs['status'][k] == 0 and recs['n_deform'][k] == orecs['M'][k]
                 tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
                 assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (sm, mode, k, recs['energy'][k], orecs['energy'][k])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: the fixtures of the reference's elliptical optimum / parameters, point evaluations, BASELINE configs[4],
+# forced protocol branches
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma'])
+def test_elliptical_optimum_and_parameters_match_reference(gpu, tag):
+    """`c{k}_psi_ell` (the reference's Energy of the 6-parameter model driven to its optimum: ALL of what the C2F operator
+    returns), the moment initialisation's energy, and the DSM optimum's parameters theta / xi (`c{k}_x_dsm`)."""
+    from superdsm_amd import testing
+    d, cfg, fps = _golden_scene(tag)
+    scene = dict(y=d['y'], atoms=d['atoms'], dsm_cfg=cfg, footprints=fps)
+    res = testing.solve_scene_gpu(scene, want_xi=True)
+    recs = res['records']
+    checked = 0
+    for k in range(len(fps)):
+        N, M = int(d[f'c{k}_N']), int(d[f'c{k}_M'])
+        psi_ell = float(d[f'c{k}_psi_ell'])
+        tol = 1e-6 * N / 1000 + 1e-5 * abs(psi_ell)
+        if float(d[f'c{k}_gnorm_ell']) < 1e-8:
+            assert abs(recs['energy_ell'][k] - psi_ell) <= tol, (k, recs['energy_ell'][k], psi_ell)
+        else:
+            assert recs['energy_ell'][k] <= psi_ell + tol                    # near-separable: no finite minimiser
+        if float(d[f'c{k}_gnorm_dsm']) < 1e-8 and float(d[f'c{k}_gnorm_ell']) < 1e-8:
+            x = d[f'c{k}_x_dsm']
+            xo = res['xi_offsets'][k]
+            th, xi = recs['theta'][k], res['xi'][xo:xo + M]
+            # the optimum is only determined to the solver's stopping accuracy (cond(Hessian) ~ 1e9 in these coordinates)
+            assert np.abs(th - x[:6]).max() <= 5e-3 * np.abs(x[:6]).max(), (k, th, x[:6])
+            if M:
+                assert np.abs(xi - x[6:]).max() <= 5e-3 * max(1.0, np.abs(x[6:]).max()), k
+            checked += 1
+    assert checked >= 6
+
+
+def test_point_evaluations_match_reference_energy(gpu):
+    """psi, grad psi and the polynomial block of the Hessian of the solve kernels' evaluators (sdsm_batch_eval) at the 21
+    parameter points of energy.npz (values of the reference's Energy incl. the exp() guard path, dsm.py:298-300)."""
+    from superdsm_amd import engine
+    d = np.load(os.path.join(G, 'energy.npz'))
+    cfg0 = json.loads(str(d['cfg']))
+    y, atoms = d['y'], d['atoms']
+    img = engine.DeviceImage(y, None, atoms, cfg0['background_margin'])
+    n_guard = 0
+    for k in range(int(d['n_cases'])):
+        deform = bool(d[f'c{k}_deform'])
+        cfg = dict(cfg0, alpha=float(d[f'c{k}_alpha']), smooth_amount=cfg0['smooth_amount'] if deform else np.inf, init='elliptical', max_iters=1)
+        batch = engine.Batch(img, [d[f'c{k}_fp'].tolist()], cfg)
+        batch.launch()
+        p = d[f'c{k}_params']
+        assert int(batch.records()['n_deform'][0]) + 6 == p.size
+        ev = batch.evaluate([p])[0]
+        val, grad, H = float(d[f'c{k}_value']), d[f'c{k}_grad'], d[f'c{k}_hessian_lower']
+        n_guard += int(d[f'c{k}_n_guarded'])
+        assert abs(ev['psi'] - val) <= 1e-10 * abs(val), (k, ev['psi'], val)
+        assert abs(ev['psi_value'] - val) <= 1e-10 * abs(val), (k, ev['psi_value'], val)
+        np.testing.assert_allclose(ev['grad'], grad, rtol=1e-10, atol=1e-10 * np.abs(grad).max())
+        np.testing.assert_allclose(np.tril(ev['hess_theta']), H[:6, :6], rtol=1e-9, atol=1e-10 * np.abs(H[:6, :6]).max())
+    assert n_guard > 0
+
+
+def test_synthetic4096_matches_oracle(gpu):
+    """BASELINE.json configs[4]: 4096x4096, ~2000 dense overlapping nuclei, every candidate (connected subsets <= 3 +
+    universes) in one batch; a sample of >= 64 candidates against the CPU oracle on all host cores."""
+    from oracle import oracle
+    from superdsm_amd import _capi, testing
+    scene = testing.make_scene('synthetic4096', max_size=3)
+    fps = scene['footprints']
+    res = testing.solve_scene_gpu(scene)
+    recs = res['records']
+    st, cnt = np.unique(recs['status'], return_counts=True)
+    assert set(st.tolist()) <= {_capi.CAND_OPTIMAL, _capi.CAND_FALLBACK, _capi.CAND_TRIVIAL}, dict(zip(st.tolist(), cnt.tolist()))
+    assert (recs['status'] == _capi.CAND_OPTIMAL).mean() > 0.99
+    n = recs['n_deform'] + 6
+    assert (n > 172).any() and ((n > 128) & (n <= 172)).any() and (n <= 40).any()       # every size class
+    ok = recs['status'] == _capi.CAND_OPTIMAL
+    assert np.isfinite(recs['energy'][ok]).all() and (recs['energy'][ok] <= recs['energy_ell'][ok] * (1 + 1e-9) + 1e-9).all()
+    order = np.argsort(recs['n_pixels'])
+    its = recs['iters_ell'] + recs['iters_dsm']
+    sample = set(order[-12:].tolist()) | set(order[:6].tolist()) | set(order[len(order) // 2 - 3:len(order) // 2 + 3].tolist())
+    sample |= set(np.argsort(recs['n_deform'])[-10:].tolist()) | set(np.argsort(its)[-12:].tolist())
+    sample |= set(np.random.default_rng(4).choice(len(fps), 24, replace=False).tolist())
+    sample = sorted(sample)
+    assert len(sample) >= 64
+    orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], [fps[i] for i in sample], scene['dsm_cfg'], nthreads=0)
+    for j, k in enumerate(sample):
+        assert (recs['n_pixels'][k], recs['n_deform'][k]) == (orecs['N'][j], orecs['M'][j]), k
+        if orecs['status'][j] == 2:
+            assert recs['status'][k] == _capi.CAND_TRIVIAL
+            continue
+        tol = 1e-6 * orecs['N'][j] / 1000 + 1e-5 * abs(orecs['energy'][j])
+        assert abs(recs['energy'][k] - orecs['energy'][j]) <= tol, (k, recs['energy'][k], orecs['energy'][j])
+        assert testing.dice(res['fragments'][k][0], res['fragments'][k][1], orecs['fg_offset'][j], ofrags[j], scene['y'].shape) >= 0.999, k
+        assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][j])
+
+
+def test_bbbc039_like_every_candidate_matches_oracle(gpu):
+    """BASELINE.json configs[1] stand-in at full size: all 501 candidates against the oracle (energies, status, masks)."""
+    from oracle import oracle
+    from superdsm_amd import testing
+    scene = testing.make_scene('bbbc039_like', max_size=3)
+    fps = scene['footprints']
+    res = testing.solve_scene_gpu(scene)
+    recs = res['records']
+    orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], fps, scene['dsm_cfg'], nthreads=0)
+    np.testing.assert_array_equal(recs['n_pixels'], orecs['N'])
+    np.testing.assert_array_equal(recs['n_deform'], orecs['M'])
+    np.testing.assert_array_equal(recs['status'], orecs['status'])
+    worst = 1.0
+    for k in range(len(fps)):
+        tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
+        assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (k, recs['energy'][k], orecs['energy'][k])
+        assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][k])
+        worst = min(worst, testing.dice(res['fragments'][k][0], res['fragments'][k][1], orecs['fg_offset'][k], ofrags[k], scene['y'].shape))
+    assert worst >= 0.999, worst
+
+
+def _two_blob_scene(seed=3, H=96, W=128):
+    rng = np.random.default_rng(seed)
+    rr, cc = np.mgrid[:H, :W]
+    y = -0.2 + 0.03 * rng.standard_normal((H, W))
+    y += 0.55 * np.exp(-(((rr - 46) / 17.0) ** 2 + ((cc - 40) / 21.0) ** 2) ** 1.5)
+    y += 0.5 * np.exp(-(((rr - 50) / 15.0) ** 2 + ((cc - 88) / 18.0) ** 2) ** 1.5)
+    atoms = np.ones((H, W), np.int32)
+    atoms[:, 64:] = 2
+    return y, atoms
+
+
+@pytest.mark.parametrize('max_iters', [1, 2, 3, 6])
+def test_iteration_cap_forces_the_elliptical_retry_and_unknown_status(gpu, max_iters):
+    """A Newton iteration cap of a few steps makes the first elliptical solve end 'unknown' -> the retry from the moment
+    initialisation (objects.py:337-355, record flag bit 0) and an 'unknown' DSM solve that still counts as optimal because
+    it is not worse than its start (objects.py:399-400).  Flags, iteration counts and energies against the oracle run with
+    the same cap."""
+    from oracle import oracle
+    from superdsm_amd import _capi, engine
+    y, atoms = _two_blob_scene()
+    cfg = dict(scale=1000, epsilon=1.0, alpha=0.033, smooth_amount=4, smooth_subsample=8, gaussian_shape_multiplier=2,
+               background_margin=8, init='elliptical', max_iters=max_iters)
+    fps = [[1], [2], [1, 2]]
+    img = engine.DeviceImage(y, None, atoms, cfg['background_margin'])
+    batch = engine.Batch(img, fps, cfg)
+    batch.launch()
+    gpu.cuda.synchronize()
+    recs = batch.records()
+    for k, fp in enumerate(fps):
+        mask = oracle.region_mask(y, None, atoms, fp, cfg['background_margin'])
+        _, info = oracle.cvxprog(y, mask, cfg)
+        assert recs['status'][k] == info['status'] == _capi.CAND_OPTIMAL
+        assert (recs['flags'][k] & 1) == info['retried'], (k, recs['flags'][k], info)
+        assert recs['iters_ell'][k] == info['iters_ell'] and recs['iters_dsm'][k] == info['iters_dsm'] <= max_iters
+        assert abs(recs['energy'][k] - info['energy']) <= 1e-7 * abs(info['energy']), (k, recs['energy'][k], info['energy'])
+        assert abs(recs['energy_ell'][k] - info['energy_ell']) <= 1e-7 * abs(info['energy_ell'])
+        assert recs['energy'][k] <= recs['energy_ell'][k] * (1 + 1e-12)
+    if max_iters <= 3:
+        assert (recs['flags'] & 1).all(), 'a cap this small must leave the first elliptical solve unfinished'
+
+
+def test_failed_dsm_solve_falls_back_and_failed_elliptical_solve_is_an_error(gpu):
+    """alpha = inf: the regulariser makes psi non-finite for M >= 1 (the reference's Energy raises, dsm.py:325-331) -> the
+    DSM solve is an 'exception' -> status fallback with the elliptical parameters (objects.py:406-410).  A non-finite
+    intensity makes the elliptical solves fail twice -> CvxprogError carrying the candidate index (objects.py:351-353)."""
+    from oracle import oracle
+    from superdsm_amd import _capi, engine, image, objects
+    y, atoms = _two_blob_scene(seed=4)
+    cfg = dict(scale=1000, epsilon=1.0, alpha=np.inf, smooth_amount=4, smooth_subsample=8, gaussian_shape_multiplier=2,
+               background_margin=8, init='elliptical')
+    fps = [[1], [2]]
+    img = engine.DeviceImage(y, None, atoms, cfg['background_margin'])
+    batch = engine.Batch(img, fps, cfg, want_xi=True)
+    batch.launch()
+    gpu.cuda.synchronize()
+    recs = batch.records()
+    frags = batch.fragments(recs)
+    ell = engine.Batch(img, fps, dict(cfg, alpha=0.033, smooth_amount=np.inf))      # the elliptical models alone
+    ell.launch()
+    gpu.cuda.synchronize()
+    erecs = ell.records()
+    efrags = ell.fragments(erecs)
+    for k, fp in enumerate(fps):
+        mask = oracle.region_mask(y, None, atoms, fp, cfg['background_margin'])
+        _, info = oracle.cvxprog(y, mask, cfg)
+        assert recs['status'][k] == _capi.CAND_FALLBACK and info['status'] == 1
+        assert recs['n_deform'][k] == info['M'] > 0
+        np.testing.assert_allclose(recs['theta'][k], erecs['theta'][k], rtol=1e-9)
+        assert abs(recs['energy_ell'][k] - erecs['energy'][k]) <= 1e-9 * abs(erecs['energy'][k])
+        assert (batch.xi_dev.cpu().numpy() == 0).all()
+        np.testing.assert_array_equal(frags[k][1], efrags[k][1])
+    # through the reference-style API a fallback is not an error: is_optimal False, counted in the status line
+    yi = image.Image.create_from_array(y, normalize=False)
+    objs = [objects.Object() for _ in fps]
+    for o, fp in zip(objs, fps):
+        o.footprint = set(fp)
+    objects.compute_objects(objs, yi, atoms, cfg, None, out='muted')
+    assert all(o.is_optimal is False for o in objs)
+    # a candidate whose elliptical solves both fail
+    y2 = y.copy()
+    y2[40, 30] = np.inf
+    cfg2 = dict(cfg, alpha=0.033)
+    img2 = engine.DeviceImage(y2, None, atoms, cfg2['background_margin'])
+    b2 = engine.Batch(img2, fps, cfg2)
+    b2.launch()
+    gpu.cuda.synchronize()
+    r2 = b2.records()
+    assert r2['status'][0] == _capi.CAND_ERROR and r2['status'][1] == _capi.CAND_OPTIMAL
+    m0 = oracle.region_mask(y2, None, atoms, fps[0], cfg2['background_margin'])
+    assert oracle.cvxprog(y2, m0, cfg2)[1]['status'] == 3
+    yi2 = image.Image.create_from_array(y2, normalize=False)
+    with pytest.raises(objects.CvxprogError) as err:
+        objects.compute_objects(objs, yi2, atoms, cfg2, None, out='muted')
+    assert err.value.cidx == 0
+
+
+def test_more_than_1018_deformation_parameters_is_reported_as_unsupported(gpu):
+    """6 + M > 1024 exceeds the solver's limit (DESIGN.md "Limits"): status UNSUPPORTED with the elliptical result -- for an
+    ordinary region and for one that is solved by a workgroup group -- and an exception through compute_objects."""
+    from oracle import oracle
+    from superdsm_amd import _capi, engine, image, objects
+    rng = np.random.default_rng(8)
+    H, W = 150, 170
+    rr, cc = np.mgrid[:H, :W]
+    y = -0.1 + 0.02 * rng.standard_normal((H, W))
+    y += 0.4 * np.exp(-(((rr - 75) / 50.0) ** 2 + ((cc - 85) / 58.0) ** 2) ** 2)
+    atoms = np.ones((H, W), np.int32)
+    atoms[:, 100:] = 2
+    cfg = dict(scale=1000, epsilon=1.0, alpha=0.05, smooth_amount=2, smooth_subsample=3, gaussian_shape_multiplier=2,
+               background_margin=12, init='elliptical')
+    fps = [[1], [2], [1, 2]]
+    img = engine.DeviceImage(y, None, atoms, cfg['background_margin'])
+    batch = engine.Batch(img, fps, cfg)
+    batch.launch()
+    gpu.cuda.synchronize()
+    recs = batch.records()
+    assert recs['n_pixels'][2] > 12288 and recs['n_pixels'][0] <= 12288
+    assert (recs['n_deform'][[0, 2]] > 1018).all() and recs['n_deform'][1] <= 1018
+    assert recs['status'][0] == recs['status'][2] == _capi.CAND_UNSUPPORTED and recs['status'][1] == _capi.CAND_OPTIMAL
+    ell = engine.Batch(img, fps, dict(cfg, smooth_amount=np.inf))
+    ell.launch()
+    gpu.cuda.synchronize()
+    erecs = ell.records()
+    for k in (0, 2):
+        assert abs(recs['energy'][k] - erecs['energy'][k]) <= 1e-6 * abs(erecs['energy'][k])
+        assert abs(recs['energy'][k] - recs['energy_ell'][k]) <= 1e-9 * abs(recs['energy'][k])
+    yi = image.Image.create_from_array(y, normalize=False)
+    o = objects.Object()
+    o.footprint = {1}
+    with pytest.raises(_capi.SdsmError):
+        objects.compute_objects([o], yi, atoms, cfg, None, out='muted')
