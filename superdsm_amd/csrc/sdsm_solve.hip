@@ -94,6 +94,7 @@ struct Cand {                       // per-candidate global pointers (already of
     double *wpool;                      // the group's block of BatchParams.wide_pool
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
+    double reg0;                        // alpha * sqrt(epsilon) * M: the regulariser's value at xi = 0 (dsm.py:325-326)
 };
 
 // The evaluators are real (non-inlined) functions and receive the candidate by reference: its fields then come out of a
@@ -108,6 +109,30 @@ __device__ __forceinline__ unsigned long long uni(unsigned long long v)
 }
 __device__ __forceinline__ double uni(double v) { return __longlong_as_double((long long)uni((unsigned long long)__double_as_longlong(v))); }
 template <class T> __device__ __forceinline__ T SDSM_GLOBAL *uni(T SDSM_GLOBAL *p) { return (T SDSM_GLOBAL *)uni((unsigned long long)p); }
+
+// The candidate's descriptor and state are the same for every lane but arrive through vector loads (the compiler cannot prove
+// the workspace read-only): move every field to SGPRs once, instead of holding ~50 VGPRs for the whole solve.
+__device__ __forceinline__ long long uni(long long v) { return (long long)uni((unsigned long long)v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ CandDesc uniform_desc(const CandDesc &d)
+{
+    CandDesc u;
+    u.crop_off = uni((long long)d.crop_off); u.ell_off = uni((long long)d.ell_off); u.mask_off = uni((long long)d.mask_off); u.xi_off = uni((long long)d.xi_off);
+    u.N = uni(d.N); u.r0 = uni(d.r0); u.c0 = uni(d.c0); u.h = uni(d.h); u.w = uni(d.w); u.fp_off = uni(d.fp_off); u.fp_len = uni(d.fp_len);
+    u.Mcap = uni(d.Mcap); u.perm_inv = uni(d.perm_inv); u.wide_g = uni(d.wide_g);
+    u.hglob_off = uni((long long)d.hglob_off); u.wide_off = uni((long long)d.wide_off);
+    return u;
+}
+__device__ __forceinline__ CandState uniform_state(const CandState &d)
+{
+    CandState u;
+    u.M = uni(d.M); u.status = uni(d.status); u.hc = uni(d.hc); u.wc = uni(d.wc); u.npos = uni(d.npos); u.zmax = uni(d.zmax);
+    u.sum_r = uni(d.sum_r); u.sum_c = uni(d.sum_c); u.sum_rr = uni(d.sum_rr); u.sum_cc = uni(d.sum_cc);
+    u.hzmax = uni(d.hzmax); u.env_size = uni(d.env_size); u.nneg = uni(d.nneg); u.pad1 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) u.gcount[j] = uni(d.gcount[j]);
+    return u;
+}
 __device__ __forceinline__ Cand uniform_cand(const Cand &c)
 {
     Cand u;
@@ -118,9 +143,17 @@ __device__ __forceinline__ Cand uniform_cand(const Cand &c)
     u.N = uni(c.N); u.zmax = uni(c.zmax); u.hzmax = uni(c.hzmax); u.env_size = uni(c.env_size);
     u.p_lo = uni(c.p_lo); u.p_hi = uni(c.p_hi); u.wg = uni(c.wg); u.wG = uni(c.wG); u.wpool = (double *)uni((unsigned long long)c.wpool);
     u.rmid = uni(c.rmid); u.cmid = uni(c.cmid); u.inv_hr = uni(c.inv_hr); u.inv_hc = uni(c.inv_hc);
-    u.scale = uni(c.scale); u.epsilon = uni(c.epsilon); u.alpha = uni(c.alpha);
+    u.scale = uni(c.scale); u.epsilon = uni(c.epsilon); u.alpha = uni(c.alpha); u.reg0 = uni(c.reg0);
     return u;
 }
+
+// The thread index as the optimiser cannot see through it: the per-thread addresses of a pass (base + tid) are then formed
+// inside the pass, not hoisted to the top of the kernel and kept alive (or spilled) across the whole solver.
+__device__ __forceinline__ int opaque_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+
+// A constant materialised where it is used: the optimiser otherwise loads the rarely used 64-bit constants of the solver logic
+// into registers at the top of the kernel and keeps (or spills) them across every pass.
+__device__ __forceinline__ double fresh(double v) { asm volatile("" : "+s"(v)); return v; }
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
 
@@ -338,7 +371,7 @@ __device__ __forceinline__ double eval_value(const Cand &c, int xo, int M)
 {
     const double *xv = SD + xo;
     double psi = 0;
-    for (int p = c.p_lo + threadIdx.x; p < c.p_hi; p += L::WGS) {
+    for (int p = c.p_lo + opaque_tid(); p < c.p_hi; p += L::WGS) {
         double yv = c.crop_y[p];
         uint32_t rc = c.crop_rc[p];
         double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
@@ -360,7 +393,7 @@ __device__ __forceinline__ double eval_value(const Cand &c, int xo, int M)
         double s2 = 0;
         for (int j = threadIdx.x; j < M; j += L::WGS) s2 += sqrt(xv[6 + j] * xv[6 + j] + c.epsilon);
         s2 = block_sum<L::NWAVES>(s2, SD + L::RED);
-        double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
+        double o2 = c.alpha * s2 - c.reg0;
         psi += o2 < 0 ? 0 : o2;
     }
     return uni(psi);                                     // every thread holds the same sum: scalar from here on (uniform control flow in the solver)
@@ -372,7 +405,7 @@ __device__ __forceinline__ double eval_value(const Cand &c, int xo, int M)
 template <class L>
 __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, double (&out)[LS_K])
 {
-    const int tid = threadIdx.x, n = 6 + M;
+    const int tid = opaque_tid(), n = 6 + M;
     const double *x = SD + L::X, *d = SD + L::D;
     double *xd = SD + L::XT;
     __syncthreads();
@@ -418,6 +451,8 @@ __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, doubl
         double tk = t0;
 #pragma unroll
         for (int k = 0; k < LS_K; k++) {
+            // four independent loss evaluations in flight keep the FP64 pipe busy; all eight would double the live registers
+            if (k == LS_K / 2) __builtin_amdgcn_sched_barrier(0);
             const double t = a0 + tk * a1;
             ps[k] += softplus_neg(t);
             tk *= LS_BETA;
@@ -450,8 +485,9 @@ __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, doubl
             for (int k = 0; k < LS_K; k++) { const double xi = xj + tk * dj; rs[k] += sqrt(xi * xi + c.epsilon); tk *= LS_BETA; }
         }
         block_sum_vec<LS_K, L::NWAVES>(rs, SD + L::RED);
+        const double reg_off = c.reg0;
 #pragma unroll
-        for (int k = 0; k < LS_K; k++) { const double o2 = c.alpha * rs[k] - c.alpha * sqrt(c.epsilon) * M; ps[k] += o2 < 0 ? 0 : o2; }
+        for (int k = 0; k < LS_K; k++) { const double o2 = c.alpha * rs[k] - reg_off; ps[k] += o2 < 0 ? 0 : o2; }
     }
 #pragma unroll
     for (int k = 0; k < LS_K; k++) out[k] = uni(ps[k]);
@@ -477,8 +513,54 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M, double r
         Hp[RBP[j] + j] += gd;
     }
     s2 = block_sum<L::NWAVES>(s2, SD + L::RED);
-    double o2 = c.alpha * s2 - c.alpha * sqrt(c.epsilon) * M;
+    double o2 = c.alpha * s2 - c.reg0;
     return o2 < 0 ? 0 : o2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Polynomial part of one pixel's contribution to psi, gradient and Hessian, kept as MOMENTS of the coordinates: with
+// q = (u^2, v^2, 2uv, 2u, 2v, 1) the 6 gradient entries sum r q_a and the 21 Hessian entries sum d q_a q_b are small multiples
+// of sum r u^a v^b (a + b <= 2: 6 sums) and sum d u^a v^b (a + b <= 4: 15 sums) -- 22 per-lane accumulators instead of 28.
+//   m[0] psi; m[1..6] r * (1, u, v, u^2, uv, v^2); m[7..21] d * (1, u, v, u^2, uv, v^2, u^3, u^2 v, u v^2, v^3, u^4, u^3 v, u^2 v^2, u v^3, v^4)
+// ---------------------------------------------------------------------------------------------------------
+#define NMOM 22
+__device__ __forceinline__ void add_moments(double (&m)[NMOM], double phi, double r, double dc, double u, double v)
+{
+    const double uu = u * u, uv = u * v, vv = v * v;
+    m[0] += phi;
+    m[1] += r; m[2] += r * u; m[3] += r * v; m[4] += r * uu; m[5] += r * uv; m[6] += r * vv;
+    const double duu = dc * uu, duv = dc * uv, dvv = dc * vv;
+    m[7] += dc; m[8] += dc * u; m[9] += dc * v; m[10] += duu; m[11] += duv; m[12] += dvv;
+    m[13] += duu * u; m[14] += duu * v; m[15] += dvv * u; m[16] += dvv * v;
+    m[17] += duu * uu; m[18] += duu * uv; m[19] += duu * vv; m[20] += dvv * uv; m[21] += dvv * vv;
+}
+// gradient entry a = GF[a] * m[GM[a]]; Hessian entry t of the packed lower triangle (a >= b, t = a (a + 1) / 2 + b) = HF[t] * m[HM[t]]
+__device__ __forceinline__ double moment_grad(const double *tot, int a)
+{
+    const int gm[6] = {4, 6, 5, 2, 3, 1};
+    const double gf[6] = {1, 1, 2, 2, 2, 1};
+    int mi = 1; double f = 1;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { mi = a == k ? gm[k] : mi; f = a == k ? gf[k] : f; }
+    return f * tot[mi];
+}
+__device__ __forceinline__ double moment_hess(const double *tot, int t)
+{
+    //                 00  10  11  20  21  22  30  31  32  33  40  41  42  43  44  50  51  52  53  54  55
+    const int hm[21] = {17, 19, 21, 18, 20, 19, 13, 15, 14, 10, 14, 16, 15, 11, 12, 10, 12, 11,  8,  9,  7};
+    const double hf[21] = {1,  1,  1,  2,  2,  4,  2,  2,  4,  4,  2,  2,  4,  4,  4,  1,  1,  2,  2,  2,  1};
+    int mi = 7; double f = 1;
+#pragma unroll
+    for (int k = 0; k < 21; k++) { mi = t == k ? hm[k] : mi; f = t == k ? hf[k] : f; }
+    return f * tot[mi];
+}
+// totals of the NMOM sums over the workgroup -> LDS array tot[NMOM] (every thread may read any of them afterwards)
+template <class L>
+__device__ __forceinline__ void moments_total(const double (&m)[NMOM], double *tot)
+{
+    block_sum_scatter<NMOM, L::NWAVES>(m, SD + L::RED);
+    if (threadIdx.x < NMOM) tot[threadIdx.x] = sum_scatter_total<NMOM, L::NWAVES>(SD + L::RED, threadIdx.x);
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -489,33 +571,27 @@ template <class L>
 __device__ __forceinline__ double eval_full_ell(const Cand &c PROF_PARAM)
 {
     long long pt = PROF_NOW();
-    const int tid = threadIdx.x;
+    const int tid = opaque_tid();
     double *Hp = hess_ptr<L>(c), *g = SD + L::G;
     const double *xv = SD + L::X;
-    double red[28];
+    double red[NMOM];
 #pragma unroll
-    for (int k = 0; k < 28; k++) red[k] = 0;
+    for (int k = 0; k < NMOM; k++) red[k] = 0;
     for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
         const double yv = c.crop_y[p];
         const uint32_t rc = c.crop_rc[p];
         const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-        const double q[6] = {u * u, v * v, 2 * (u * v), 2 * u, 2 * v, 1.0};
-        const double Sv = q[0] * xv[0] + q[1] * xv[1] + q[2] * xv[2] + q[3] * xv[3] + q[4] * xv[4] + xv[5];
+        const double Sv = (u * u) * xv[0] + (v * v) * xv[1] + (2 * (u * v)) * xv[2] + (2 * u) * xv[3] + (2 * v) * xv[4] + xv[5];
         double phi, r, dc;
         loss_terms(yv, Sv, &phi, &r, &dc);
-        red[0] += phi;
-#pragma unroll
-        for (int a = 0; a < 6; a++) red[1 + a] += r * q[a];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = 0; b <= a; b++) red[7 + a * (a + 1) / 2 + b] += dc * q[a] * q[b];   // static index: stays in registers
+        add_moments(red, phi, r, dc, u, v);
     }
     PROF_ADD(0, pt);
-    block_sum_scatter<28, L::NWAVES>(red, SD + L::RED);
-    if (tid < 6) g[tid] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 1 + tid);
-    if (tid < 21) Hp[tid] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 7 + tid);   // packed lower triangle of a 6x6 matrix = the same enumeration order
-    double psi = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 0);
+    double *tot = SD + L::TMP;                           // TMP is free outside factor_solve
+    moments_total<L>(red, tot);
+    if (tid < 6) g[tid] = moment_grad(tot, tid);
+    if (tid < 21) Hp[tid] = moment_hess(tot, tid);       // packed lower triangle of a 6x6 matrix = the same enumeration order
+    double psi = tot[0];
     __syncthreads();
     if (c.wG > 1) {
         double *tmp = SD + L::TMP;
@@ -536,7 +612,7 @@ template <class L>
 __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double reg_mu PROF_PARAM)
 {
     long long pt = PROF_NOW();
-    const int tid = threadIdx.x;
+    const int tid = opaque_tid();
     const int n = 6 + M;
     double *Hp = hess_ptr<L>(c), *g = SD + L::G;
     const double *xv = SD + L::X;
@@ -547,9 +623,9 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
 #pragma unroll
     for (int b = 0; b < 6; b++) rbt[b] = __builtin_amdgcn_readfirstlane(rbp[M + b]);
     __syncthreads();
-    double red[28];                                      // psi, g_theta[6], 6x6 lower triangle (21)
+    double red[NMOM];                                    // psi and the coordinate moments of r and d (add_moments)
 #pragma unroll
-    for (int k = 0; k < 28; k++) red[k] = 0;
+    for (int k = 0; k < NMOM; k++) red[k] = 0;
     const int zm = M > 0 ? c.zmax : 0;
     const bool in_regs = zm <= ZREG;
     for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
@@ -570,13 +646,7 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
         FINE_ADD(9);
         double phi, r, dc;
         loss_terms(yv, Sv, &phi, &r, &dc);
-        red[0] += phi;
-#pragma unroll
-        for (int a = 0; a < 6; a++) red[1 + a] += r * q[a];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = 0; b <= a; b++) red[7 + a * (a + 1) / 2 + b] += dc * q[a] * q[b];
+        add_moments(red, phi, r, dc, u, v);
         FINE_ADD(10);
         if (dc != 0 || r != 0) {
             const int hnz = (int)(meta >> 16);
@@ -638,14 +708,15 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
         FINE_ADD(12);
     }
     PROF_ADD(0, pt);
-    block_sum_scatter<28, L::NWAVES>(red, SD + L::RED);
-    if (tid < 6) g[tid] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 1 + tid);
+    double *tot = SD + L::TMP;                           // TMP is free outside factor_solve
+    moments_total<L>(red, tot);
+    if (tid < 6) g[tid] = moment_grad(tot, tid);
     if (tid < 21) {
         int a = 0;
         while ((a + 1) * (a + 2) / 2 <= tid) a++;
-        Hp[rbp[M + a] + M + (tid - a * (a + 1) / 2)] = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 7 + tid);   // theta-theta block: columns M .. M + a of row M + a
+        Hp[rbp[M + a] + M + (tid - a * (a + 1) / 2)] = moment_hess(tot, tid);   // theta-theta block: columns M .. M + a of row M + a
     }
-    double psi = sum_scatter_total<28, L::NWAVES>(SD + L::RED, 0);
+    double psi = tot[0];
     __syncthreads();
     if (c.wG > 1) {                                      // partial Hessian / gradient / psi of this member's slice -> totals
         double *tmp = SD + L::TMP;
@@ -683,7 +754,7 @@ template <class L>
 __device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in, double *lam2 PROF_PARAM)
 {
     long long pf = PROF_NOW();
-    const int tid = threadIdx.x;
+    const int tid = opaque_tid();
     const int n = 6 + M;
     double *Hp = hess_ptr<L>(c), *g = SD + L::G, *yrow = SD + L::YROW, *d = SD + L::D, *dg = SD + L::TMP, *zl = SD + L::XT;   // XT is free between line searches
     const int *rbp = RBP, *fstp = FSTP, *rendp = RENDP;
@@ -958,7 +1029,7 @@ template <class L>
 __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, double *psi_out, int *iters_out, int *ev_value, int *ev_full PROF_PARAM)
 {
     enum { EV_STEP = 0, EV_SPEC = 1, EV_RETRY = 2, EV_CHECK = 3 };
-    const int tid = threadIdx.x, n = 6 + M;
+    const int tid = opaque_tid(), n = 6 + M;
     double *x = SD + L::X, *xt = SD + L::XT, *d = SD + L::D, *xb = SD + L::YROW;   // YROW is only live inside factor_solve
     int status = 1, iters = 0, why = EV_STEP, retries = 0;
     double mu = M > 0 ? 1.0 : 0.0, mu_spec = 0, tprev = 0, tau = 0;
@@ -972,7 +1043,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         bool line = false;
         double t0 = M == 0 ? LS_T0_ELL : 1.0;
         if (why == EV_SPEC) {
-            if (isfinite(pe) && c.scale * pe <= f - LS_ALPHA * lam2) { psi = pe; tprev = 1.0; mu = mu_spec; why = EV_STEP; }
+            if (isfinite(pe) && c.scale * pe <= f - fresh(LS_ALPHA) * lam2) { psi = pe; tprev = 1.0; mu = mu_spec; why = EV_STEP; }
             else {                                           // back to x; t = 1 is known to fail
                 __syncthreads();
                 for (int i = tid; i < n; i += L::WGS) x[i] = xb[i];
@@ -983,7 +1054,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         if (!line) {
             if (why != EV_RETRY) {
                 if (iters >= max_iters) { status = 1; break; }
-                f = c.scale * psi;
+                f = uni(c.scale * psi);
                 if (!isfinite(f)) { status = 2; break; }
                 tau = 0; retries = 0;
             }
@@ -991,14 +1062,14 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
             const int fs = factor_solve<L>(c, M, tau, &lam2u PROF_ARG);
             if (fs == 1 && retries < 11) {                   // escalating diagonal shift (same schedule as the oracle)
                 retries++;
-                tau = tau == 0 ? 1e-12 : tau * 100;
+                tau = uni(tau == 0 ? fresh(1e-12) : tau * fresh(100.0));
                 why = EV_RETRY;
                 continue;
             }
             if (fs != 0) { status = 2; break; }
-            lam2 = c.scale * lam2u;
+            lam2 = uni(c.scale * lam2u);
             PROF_ADD(3, pt);
-            const bool conv = lam2 * 0.5 <= NEWTON_ABSTOL + NEWTON_RELTOL * fabs(f);
+            const bool conv = lam2 * 0.5 <= fresh(NEWTON_ABSTOL) + fresh(NEWTON_RELTOL) * fabs(f);
             if (conv && mu > 0) { mu = 0; why = EV_CHECK; continue; }
             iters++;
             if (conv) {
@@ -1018,7 +1089,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
             }
             if (tprev == 1.0 || (iters == 1 && M > 0)) {
                 mu_spec = mu * MU_DECAY;
-                mu_spec = mu_spec < MU_MIN ? 0 : mu_spec;
+                mu_spec = uni(mu_spec < fresh(MU_MIN) ? 0 : mu_spec);
                 __syncthreads();
                 for (int i = tid; i < n; i += L::WGS) { const double xi = x[i]; xb[i] = xi; x[i] = xi + d[i]; }
                 __syncthreads();
@@ -1037,8 +1108,8 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
             double tk = t0;
 #pragma unroll
             for (int k = 0; k < LS_K; k++) {
-                const double ft = c.scale * fs[k];
-                if (isfinite(ft) && ft <= f - LS_ALPHA * tk * lam2 && ft < fbest) { fbest = ft; tbest = tk; accepted = true; }
+                const double ft = uni(c.scale * fs[k]);
+                if (isfinite(ft) && ft <= f - fresh(LS_ALPHA) * tk * lam2 && ft < fbest) { fbest = ft; tbest = tk; accepted = true; }
                 tk *= LS_BETA;
             }
             t0 = tk;
@@ -1049,7 +1120,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         __syncthreads();
         tprev = tbest;
         if (M > 0) {
-            if (tbest >= 1) { mu *= MU_DECAY; mu = mu < MU_MIN ? 0 : mu; }
+            if (tbest >= 1) { mu *= MU_DECAY; mu = uni(mu < fresh(MU_MIN) ? 0 : mu); }
             else mu = 1.0;
         }
         why = EV_STEP;
@@ -1071,6 +1142,19 @@ __device__ __forceinline__ void reparam(const double *th, double p0, double p1, 
     out[5] = a1 * o0 * o0 + a2 * o1 * o1 + 2 * a3 * o0 * o1 + 2 * b1 * o0 + 2 * b2 * o1 + cc;
 }
 
+// Affine map between the candidate's local coordinates and the full-image-normalised ones: x0 = r / (H-1) = P0 u + O0.
+// Computed where it is used (by one lane, behind an opaque value) instead of being kept in registers across the solver.
+struct Frame { double z0, z1, P0, P1, O0, O1; };
+__device__ __forceinline__ Frame make_frame(const Cand &c, int H, int W)
+{
+    Frame f;
+    double one = 1.0;
+    asm volatile("" : "+v"(one), "+s"(H), "+s"(W));
+    f.z0 = H > 1 ? H - one : one; f.z1 = W > 1 ? W - one : one;
+    f.P0 = one / (c.inv_hr * f.z0); f.P1 = one / (c.inv_hc * f.z1); f.O0 = c.rmid / f.z0; f.O1 = c.cmid / f.z1;
+    return f;
+}
+
 }  // namespace
 
 // A candidate belongs to the FIRST class whose limits (6 + M <= NMAX and Hessian envelope <= EMAX doubles) it meets; the
@@ -1082,12 +1166,12 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
                                                               uint32_t *masks, double *xi_out)
 {
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
-    const int tid = threadIdx.x;
-    const int entry = P.order[blockIdx.x];
+    int tid = threadIdx.x;                                   // re-derived (opaque_tid) at the start of every section: nothing per-thread is kept across the solver
+    const int entry = uni(P.order[blockIdx.x]);
     const int ci = WIDE ? entry & 0xffffff : entry;
     const int wg = WIDE ? (entry >> 24) & 0xff : 0;
-    const CandDesc cd = P.cand[ci];
-    const CandState st = P.state[ci];
+    const CandDesc cd = uniform_desc(P.cand[ci]);
+    const CandState st = uniform_state(P.state[ci]);
     sdsm_record *rec = &records[ci];
 
     if (st.status != ST_OK) {
@@ -1137,14 +1221,11 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = Mfull > 0 ? st.gcount[j] : 0;
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
-    c.epsilon = P.epsilon; c.alpha = P.alpha;
+    c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * Mfull;   // (only read by passes with M = Mfull > 0)
     // local frame: centre of the bounding box, half extents
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
     c.inv_hr = 1.0 / (half_r < 1 ? 1 : half_r); c.inv_hc = 1.0 / (half_c < 1 ? 1 : half_c);
-    // normalised image coordinate x0 = r / (H-1) = P0 * u + O0
-    const double z0 = P.H > 1 ? P.H - 1.0 : 1.0, z1 = P.W > 1 ? P.W - 1.0 : 1.0;
-    const double P0 = 1.0 / (c.inv_hr * z0), P1 = 1.0 / (c.inv_hc * z1), O0 = c.rmid / z0, O1 = c.cmid / z1;
     double *x = SD + L::X, *xt = SD + L::XT;
     c = uniform_cand(c);                                        // per-candidate scalars and pointers into SGPRs (they are computed by vector instructions)
 
@@ -1167,29 +1248,37 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     int s_prev = 0;
     for (int phase = P.init_elliptical ? 0 : 2; phase < 3; phase++) {
         int M = 0;
+        tid = opaque_tid();
         if (phase == 1) {
             if (have && s_prev == 0) continue;                                  // pass 1 was optimal
             r.flags |= 1;
-            double cnt = (double)st.npos;
-            double mr = (double)st.sum_r / cnt, mc = (double)st.sum_c / cnt;
-            double cr = rint(mr), cc2 = rint(mc);                               // np.round: half to even
-            double c0 = cr / z0, c1 = cc2 / z1;
-            // exact integer second moments: n * sum(r^2) - (sum r)^2
-            double vr = ((double)st.sum_rr * cnt - (double)st.sum_r * (double)st.sum_r) / (cnt * cnt);
-            double vc = ((double)st.sum_cc * cnt - (double)st.sum_c * (double)st.sum_c) / (cnt * cnt);
-            double h0 = sqrt(vr < 0 ? 0 : vr) / z0, h1 = sqrt(vc < 0 ? 0 : vc) / z1;
-            h0 = h0 < 1e-8 ? 1e-8 : h0; h1 = h1 < 1e-8 ? 1e-8 : h1;
-            double e0 = 1 / (h0 * h0), e1 = 1 / (h1 * h1);
-            double b0 = e0 * c0, b1 = e1 * c1, cterm = c0 * b0 + c1 * b1 - 1;
-            double thg[6] = {-e0, -e1, 0, b0, b1, -cterm}, thl[6];
-            reparam(thg, P0, P1, O0, O1, thl);
             __syncthreads();
-            if (tid < 6) xt[tid] = thl[tid];
+            if (tid == 0) {                                                     // one lane: the divisions and square roots of the moment model need many registers
+                const Frame fr = make_frame(c, P.H, P.W);
+                const double z0 = fr.z0, z1 = fr.z1;
+                int q_n = st.npos;
+                unsigned long long q_r = st.sum_r, q_c = st.sum_c, q_rr = st.sum_rr, q_cc = st.sum_cc;
+                asm volatile("" : "+s"(q_n), "+s"(q_r), "+s"(q_c), "+s"(q_rr), "+s"(q_cc));
+                const double cnt = (double)q_n;                                 // keeps the whole computation inside this branch (it is pure: the optimiser would hoist it to the top of the kernel for every lane)
+                double mr = (double)q_r / cnt, mc = (double)q_c / cnt;
+                double cr = rint(mr), cc2 = rint(mc);                           // np.round: half to even
+                double c0 = cr / z0, c1 = cc2 / z1;
+                // exact integer second moments: n * sum(r^2) - (sum r)^2
+                double vr = ((double)q_rr * cnt - (double)q_r * (double)q_r) / (cnt * cnt);
+                double vc = ((double)q_cc * cnt - (double)q_c * (double)q_c) / (cnt * cnt);
+                double h0 = sqrt(vr < 0 ? 0 : vr) / z0, h1 = sqrt(vc < 0 ? 0 : vc) / z1;
+                h0 = h0 < 1e-8 ? 1e-8 : h0; h1 = h1 < 1e-8 ? 1e-8 : h1;
+                double e0 = 1 / (h0 * h0), e1 = 1 / (h1 * h1);
+                double b0 = e0 * c0, b1 = e1 * c1, cterm = c0 * b0 + c1 * b1 - 1;
+                double thg[6] = {-e0, -e1, 0, b0, b1, -cterm}, thl[6];
+                reparam(thg, fr.P0, fr.P1, fr.O0, fr.O1, thl);
+                for (int i = 0; i < 6; i++) xt[i] = thl[i];
+            }
             __syncthreads();
             double vinit = eval_value<L>(c, L::XT, 0);
             ev_value++;
             if (vinit > psi_ell) continue;                                      // objects.py:341-342
-            if (tid < 6) x[tid] = thl[tid];
+            if (tid < 6) x[tid] = xt[tid];
             __syncthreads();
         } else if (phase == 2) {
             if (P.init_elliptical && !have) { status_final = SDSM_CAND_ERROR; break; }   // CvxprogError (objects.py:351-353)
@@ -1199,10 +1288,11 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
             if (M > 0) {                                                         // envelope of the Hessian (setup kernel)
                 int *rbp = RBP, *fstp = FSTP, *rendp = RENDP;
                 const int exi = efull - 6 * M - 21;
-                for (int a = tid; a < M; a += L::WGS) { rbp[a] = P.env_rb[cd.xi_off + a]; fstp[a] = P.env_fst[cd.xi_off + a]; }
+                const int otid = opaque_tid();                                   // (addresses formed here, not at the top of the kernel)
+                for (int a = otid; a < M; a += L::WGS) { rbp[a] = P.env_rb[cd.xi_off + a]; fstp[a] = P.env_fst[cd.xi_off + a]; }
                 if (tid < 6) { rbp[M + tid] = exi + tid * M + tid * (tid + 1) / 2; fstp[M + tid] = 0; }
                 __syncthreads();
-                for (int pnl = tid; SDSM_PANEL * pnl < M; pnl += L::WGS) {      // last xi row whose envelope reaches the panel's first column
+                for (int pnl = otid; SDSM_PANEL * pnl < M; pnl += L::WGS) {      // last xi row whose envelope reaches the panel's first column
                     int lo = SDSM_PANEL * pnl, hi = M - 1;                       // fst is non-decreasing, fst[first column] <= first column
                     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (fstp[mid] <= SDSM_PANEL * pnl) lo = mid; else hi = mid - 1; }
                     rendp[pnl] = lo;
@@ -1213,6 +1303,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         }
         double psi; int its;
         int s = newton<L>(c, M, P.max_iters, &psi, &its, &ev_value, &ev_full PROF_ARG);
+        tid = opaque_tid();
 #ifdef SDSM_PROFILE
         if (phase < 2) { prof_acc[6] = PROF_NOW() - prof_t_start; }
 #endif
@@ -1233,7 +1324,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
                 __syncthreads();
                 const double vi = eval_value<L>(c, L::XT, Mfull);
                 ev_value++;
-                if (s == 2 || psi > vi * (1 + 1e-12)) {
+                if (s == 2 || psi > vi * fresh(1 + 1e-12)) {
                     fallback = true;
                     for (int i = tid; i < NMAX; i += L::WGS) x[i] = xt[i];
                     __syncthreads();
@@ -1247,14 +1338,15 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     if (unsupported && status_final != SDSM_CAND_ERROR) status_final = SDSM_CAND_UNSUPPORTED;
 
     // ---- mask tail (objects.py:198-209) ----------------------------------------------------------
+    tid = opaque_tid();
     const int mwords = (cd.h * cd.w + 31) / 32;
     uint32_t *mk = masks + cd.mask_off;
-    if (!WIDE) for (int i = tid; i < mwords; i += L::WGS) mk[i] = 0;         // (a group's member 0 cleared it before the first all-reduce)
+    if (!WIDE) for (int i = opaque_tid(); i < mwords; i += L::WGS) mk[i] = 0;         // (a group's member 0 cleared it before the first all-reduce)
     __syncthreads();
     int rmin = 1 << 30, rmax = -1, cmin = 1 << 30, cmax = -1;
     int onb = 0;
     if (status_final != SDSM_CAND_ERROR) {
-        for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
+        for (int p = c.p_lo + opaque_tid(); p < c.p_hi; p += L::WGS) {
             uint32_t rc = c.crop_rc[p];
             int pr = rc >> 16, pc = rc & 0xffffu;
             double u = ((double)pr - c.rmid) * c.inv_hr, v = ((double)pc - c.cmid) * c.inv_hc;
@@ -1299,11 +1391,12 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         if (c.wg != 0) return;                                               // member 0 writes the record
     }
 
-    if (xi_out) for (int j = tid; j < st.M; j += L::WGS) xi_out[cd.xi_off + j] = j < Mfull ? x[6 + j] : 0;
+    if (xi_out) for (int j = opaque_tid(); j < st.M; j += L::WGS) xi_out[cd.xi_off + j] = j < Mfull ? x[6 + j] : 0;
     if (tid == 0) {
         // local basis -> full-image-normalised theta:  u = (x0 - O0) / P0
+        const Frame fr = make_frame(c, P.H, P.W);
         double thl[6] = {x[0], x[1], x[2], x[3], x[4], x[5]}, thg[6];
-        reparam(thl, 1 / P0, 1 / P1, -O0 / P0, -O1 / P1, thg);
+        reparam(thl, 1 / fr.P0, 1 / fr.P1, -fr.O0 / fr.P0, -fr.O1 / fr.P1, thg);
         for (int i = 0; i < 6; i++) r.theta[i] = thg[i];
         r.energy = status_final == SDSM_CAND_ERROR ? NAN : psi_final;
         r.status = status_final;
@@ -1334,8 +1427,8 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
     const int tid = threadIdx.x;
     const int ci = blockIdx.x;
-    const CandDesc cd = P.cand[ci];
-    const CandState st = P.state[ci];
+    const CandDesc cd = uniform_desc(P.cand[ci]);
+    const CandState st = uniform_state(P.state[ci]);
     if (st.status != ST_OK || st.M < 0 || 6 + st.M > SDSM_MAX_N_SOLVE) return;            // out stays NaN (filled by the host)
     const int M = st.M, n = 6 + M;
     const int efull = M > 0 ? st.env_size : 21;
@@ -1350,7 +1443,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = M > 0 ? st.gcount[j] : 0;
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
-    c.scale = P.scale / cd.N; c.epsilon = P.epsilon; c.alpha = P.alpha;
+    c.scale = P.scale / cd.N; c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * M;
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
     c.inv_hr = 1.0 / (half_r < 1 ? 1 : half_r); c.inv_hc = 1.0 / (half_c < 1 ? 1 : half_c);
