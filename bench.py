@@ -1,15 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: candidate DSM solves per second on the BBBC039-like 520x696 image (BASELINE.json
-configs[1]), all candidates of the image in one batch per step, 1..N MI355X (one process per GPU).
+"""Headline benchmark: candidate DSM solves per second on the BBBC039-like 520x696 image (BASELINE.json configs[1]),
+1..N MI355X (one process per GPU).
 
-A "step" = one pass of the hot path over the image's whole candidate list with the image already resident in
-HBM: region crops, greedy grids + G~ rows, elliptical + DSM solves, masks, records (one sdsm_batch_launch),
-plus -- for N > 1 -- the single gather of the fixed-size records and bit-packed masks to rank 0 over RCCL.
-Prints ONE JSON line on rank 0.
+A "step" = one pass of the hot path over one batch of synthetic input with everything already resident in HBM: ONE
+launch of the engine over the complete candidate lists of `--images` (default 8) BBBC039-like images -- region crops, greedy
+grids + G~ rows, elliptical + DSM solves, masks, records (one sdsm_batch_launch_multi) -- plus, for N > 1, the single gather of
+the fixed-size records and bit-packed masks to rank 0 over RCCL.  One image alone (501 candidates) cannot fill 256 compute
+units; the multi-image plan is the production answer to that (an image set, or the same generation of several images), it needs
+neither several streams nor an environment variable.
+
+`python bench.py --gpus N` with WORLD_SIZE unset starts the N ranks itself (fresh child processes, created before anything
+touches the GPU); under torchrun it is one rank.  Prints ONE JSON line on rank 0.
+
+Other workloads: --workload {gowt1_like,nih3t3_like,synthetic4096,synthetic256} (one image per step);
+--mode image_set: BASELINE.json configs[3] -- a set of NIH3T3-like images dealt to the ranks, every rank runs the
+global-energy-minimisation stage on its images in lock step (process_many), one gather of the results at the end.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -17,73 +29,183 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# Independent steps are queued on separate HIP streams; ROCm maps streams onto 4 hardware queues by default and
-# kernels of streams that share a queue serialise.  Must be set before the HIP runtime initialises.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=48)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='bbbc039_like')
+    ap.add_argument('--mode', default='solves', choices=['solves', 'image_set'])
+    ap.add_argument('--images', type=int, default=None, help='images per plan = per step (default: 8 for bbbc039_like / synthetic256, else 1)')
     ap.add_argument('--max-size', type=int, default=3, help='candidates = connected atom subsets up to this size + universes')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
+    ap.add_argument('--repeats', type=int, default=5, help='the timed region of --steps steps is repeated; the median is reported')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of each CPU baseline variant')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--inflight', type=int, default=8, help='independent steps (images) in flight on separate streams; 1 = strictly sequential steps')
+    ap.add_argument('--no-extras', action='store_true', help='skip the stage / compute_objects / preprocessing timings')
+    ap.add_argument('--inflight', type=int, default=1, help='independent steps in flight on separate streams (1 = strictly sequential launches)')
+    ap.add_argument('--dry-run', action='store_true', help='rendezvous and reporting only, no GPU work (CPU test of the N-rank plumbing)')
     return ap.parse_args()
 
 
-def cpu_baseline(scene, budget_s):
-    """Oracle (CPU restatement, kind "port") on the same candidate list, one OpenMP thread per candidate on every
-    host core this process may use; the list is repeated until about `budget_s` seconds of wall time are spent."""
+# ---------------------------------------------------------------------------------------------------------------------------
+# N ranks from one command line
+# ---------------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """Parent of `python bench.py --gpus N`: starts N fresh child processes (nothing here has touched the GPU), one rank each,
+    passes rank 0's JSON line through and returns the largest exit code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    for line in out0.decode().splitlines():                   # the JSON line to stdout, anything a library printed (gloo's connection notes) to stderr
+        (sys.stdout if line.startswith('{') else sys.stderr).write(line + '\n')
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = CPU restatement of the reference path, kind "port")
+# ---------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(scene, n_images, budget_s):
+    """The oracle on the same work as one GPU step -- the candidates of all `n_images` images in ONE OpenMP loop, one candidate
+    per worker (Ray: one task per core, objects.py:280) -- in two variants: a worker per core, and cores / 2 workers with 2 threads
+    each (MKL_NUM_THREADS: 2 of the reference's task specs, examples/BBBC039/task.json:4).  Each variant is a bounded sample."""
     from oracle import oracle
-    fps = scene['footprints']
+    fps = scene['footprints'] * n_images
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    t0 = time.time()
-    oracle.compute_objects(scene['y'], None, scene['atoms'], fps, scene['dsm_cfg'], nthreads=cores)
-    t_once = time.time() - t0
-    reps = int(max(1, min(200, round(budget_s / max(t_once, 1e-3)))))
-    t0 = time.time()
-    for _ in range(reps):
-        oracle.compute_objects(scene['y'], None, scene['atoms'], fps, scene['dsm_cfg'], nthreads=cores)
-    dt = time.time() - t0
-    return dict(value=reps * len(fps) / dt, unit='candidate solves/s', cores=cores, kind='port',
-                sample=f'all {len(fps)} candidates of the same image x {reps} passes, one OpenMP thread per candidate, {dt:.1f} s wall')
+    out = {}
+    for key, workers, inner in (('per_core', cores, 1), ('half_cores_x2', max(1, cores // 2), 2)):
+        t0 = time.time()
+        oracle.compute_objects(scene['y'], None, scene['atoms'], fps, scene['dsm_cfg'], nthreads=workers, inner_threads=inner)
+        t_once = time.time() - t0
+        reps = int(max(1, min(50, round(budget_s / max(t_once, 1e-3)))))
+        t0 = time.time()
+        for _ in range(reps):
+            oracle.compute_objects(scene['y'], None, scene['atoms'], fps, scene['dsm_cfg'], nthreads=workers, inner_threads=inner)
+        dt = time.time() - t0
+        out[key] = dict(value=reps * len(fps) / dt, workers=workers, threads_per_worker=inner,
+                        sample=f'{len(fps)} candidates ({n_images} images x {len(scene["footprints"])}) x {reps} passes in one OpenMP loop, {dt:.1f} s wall')
+    best = max(out.values(), key=lambda v: v['value'])
+    return dict(value=best['value'], unit='candidate solves/s', cores=cores, kind='port', sample=best['sample'],
+                variants=out, note='CPU restatement of the reference path (oracle/), not the reference itself and not the target')
 
 
+def cpu_stage_wall(scene, beta, pruning):
+    """GlobalEnergyMinimization.process with every batch solved by the oracle on all host cores: the CPU wall clock per image."""
+    from oracle import oracle
+    from superdsm_amd import config, globalenergymin
+    import unittest.mock as mock
+
+    def oracle_compute(objs, y, atoms, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None):
+        objs = list(objs)
+        if not objs:
+            return
+        recs, frags, _ = oracle.compute_objects(y.model, None, atoms, [sorted(o.footprint) for o in objs], dsm_cfg, nthreads=0)
+        for o, r, f in zip(objs, recs, frags):
+            o.energy, o.is_optimal, o.on_boundary, o.processing_time = float(r['energy']), bool(r['is_optimal']), bool(r['on_boundary']), 0
+            o.fg_offset, o.fg_fragment = np.array(r['fg_offset']), f
+
+    stage = globalenergymin.GlobalEnergyMinimization()
+    data = dict(y=scene['y'], y_mask=np.ones(scene['y'].shape, bool), atoms=scene['atoms'], adjacencies=scene['adjacencies'], dsm_cfg=scene['dsm_cfg'])
+    cfg = config.Config({'global-energy-minimization': {'beta': beta, 'pruning': pruning}})
+    with mock.patch.object(globalenergymin, 'compute_objects', oracle_compute):
+        t0 = time.perf_counter()
+        stage(data, cfg, out='muted')
+        dt = time.perf_counter() - t0
+    return dt * 1e3, data['performance'].overall_computed_object_count
+
+
+def source_hash():
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, 'superdsm_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(workload, n_images):
+    """HBM bytes per launch of the solve kernels from the PMC passes of THIS round's sources (profiles/r*_pmc_summary.json, written
+    by tools/summarize_profiles.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command): only if the summary was
+    taken from the kernel sources that are running now, else None."""
+    best = None
+    for f in sorted(os.listdir(os.path.join(ROOT, 'profiles'))):
+        if f.endswith('_pmc_summary.json'):
+            try:
+                d = json.load(open(os.path.join(ROOT, 'profiles', f)))
+            except Exception:
+                continue
+            if d.get('source_hash') == source_hash() and d.get('workload') == workload and d.get('images_per_launch') == n_images:
+                best = d.get('solve_hbm_bytes_per_launch')
+    return best
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.inflight > 4:
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # ROCm maps streams onto 4 hardware queues by default
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (the DSM solve path has no CPU fallback)'
-    # rehearsal on a box with fewer GPUs than ranks: SDSM_BENCH_BACKEND=gloo shares the visible devices round-robin
-    backend = os.environ.get('SDSM_BENCH_BACKEND', 'nccl')
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()                           # (does not initialise the GPU)
+    # fewer GPUs than ranks (rehearsal on a one-GPU box) or no GPU at all (--dry-run on a CPU box): gloo moves host memory
+    backend = os.environ.get('SDSM_BENCH_BACKEND', 'nccl' if ndev >= world and not args.dry_run else 'gloo')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.dry_run:
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({'metric': 'candidate DSM solves/sec', 'value': 0.0, 'unit': 'candidate solves/s', 'n_gpus': world, 'steps': args.steps,
+                              'warmup': args.warmup, 'ms_per_step': float(t.item()), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                              'dtype': 'f64', 'data': 'none (dry run of the rank plumbing)', 'config': {'workload': 'dry-run', 'backend': backend}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the DSM solve path has no CPU fallback)'
+    torch.cuda.set_device(local_rank % ndev)
+    if args.mode == 'image_set':
+        return image_set_mode(args, world, rank, backend)
 
     from superdsm_amd import _capi, engine, testing
     from superdsm_amd import dist as sdist
 
     scene = testing.make_scene(args.workload, max_size=args.max_size)
-    fps = scene['footprints']
-    img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
-    # Steps are independent (in production: different images); up to `inflight` of them are queued on separate streams,
-    # each with its own workspace / record / mask buffers, so that the GPU is not idle while one image's slowest
-    # candidate finishes.  Every step still is one full pass of the hot path over the whole candidate list.
+    fps1 = scene['footprints']
+    n_images = args.images if args.images else (8 if args.workload in ('bbbc039_like', 'synthetic256') else 1)
+    margin = scene['dsm_cfg']['background_margin']
+    # `n_images` images per step, each with its own copy of y / atoms in HBM (synthetic: the same content)
+    imgs = [engine.DeviceImage(scene['y'], None, scene['atoms'], margin) for _ in range(n_images)]
+    fps = fps1 * n_images
+    image_of = np.repeat(np.arange(n_images, dtype=np.int32), len(fps1))
     nfl = max(1, min(args.inflight, args.steps))
-    batches = [engine.Batch(img, fps, scene['dsm_cfg']) for _ in range(nfl)]
+    batches = [engine.Batch(imgs, fps, scene['dsm_cfg'], image_of=image_of) for _ in range(nfl)]
     streams = [torch.cuda.Stream() for _ in range(nfl)]
-    gathers = [sdist.RecordGather(b, world, rank) if world > 1 else None for b in batches]
+    sizes = [[batches[0].records_dev.numel(), batches[0].masks_dev.numel()]] * world       # every rank has the same plan: nothing to exchange
+    gathers = [sdist.RecordGather(b, world, rank, sizes=sizes) if world > 1 else None for b in batches]
     batch = batches[0]
     L = _capi.lib()
 
@@ -97,45 +219,39 @@ def main():
             torch.cuda.default_stream().wait_stream(streams[k])
             gathers[k].run()
 
-    for k in range(nfl):                       # untimed: touch every in-flight slot once (first launch of a plan: kernel attributes,
-        step(k)                                # lazy allocations), so that --warmup smaller than --inflight does not time cold slots
+    for k in range(nfl):                       # untimed: first launch of every plan (kernel attributes, side streams)
+        step(k)
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # latency of ONE step with nothing else in flight (wall clock per image), scheduled for latency: the largest regions
-    # get a 512-thread workgroup each (sdsm_plan_set_latency_mode; same results, fewer solves per second under load)
-    lat = engine.Batch(img, fps, scene['dsm_cfg'], latency_mode=True)
-    lat.launch()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    lat.launch()
-    torch.cuda.synchronize()
-    single_ms = (time.perf_counter() - t1) * 1e3
-    del lat
+    region_ms = []
+    for _ in range(max(1, args.repeats)):      # the timed region: EXACTLY --steps steps, barrier + synchronize on both sides
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        region_ms.append(dt * 1e3)
+    dt = float(np.median(region_ms)) * 1e-3
+
+    # kernel-level timing with HIP events on the launch stream (one launch at a time)
     L.sdsm_enable_kernel_timing(1)
-    solve_ms = []
-    # kernel-level timing with HIP events on the launch stream: a few extra, separately timed launches
-    for _ in range(min(5, args.steps)):
+    solve_ms, setup_ms = [], []
+    for _ in range(5):
         batch.launch()
         solve_ms.append(L.sdsm_last_solve_kernel_ms())
-    setup_ms = L.sdsm_last_setup_kernel_ms()
+        setup_ms.append(L.sdsm_last_setup_kernel_ms())
     L.sdsm_enable_kernel_timing(0)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
     recs = batch.records()
     n_total = len(fps) * world
     value = n_total * args.steps / dt
@@ -146,37 +262,160 @@ def main():
     # FP64-vector cross-check of the Hessian phase: flops_c = E_c N_c (4 (6 + z) + 20) + H_c N_c (6 + z)^2, z ~ 11
     z = 11.0
     flops = float((evals * recs['n_pixels'] * (4 * (6 + z) + 20)).sum() + (recs['evals_full'].astype(np.int64) * recs['n_pixels'] * (6 + z) ** 2).sum())
-    traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
-    if os.path.exists(pmc_path) and args.workload == 'bbbc039_like':
-        try:
-            traffic = json.load(open(pmc_path)).get('solve_hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
     out = {
         'metric': 'candidate DSM solves/sec', 'value': value, 'unit': 'candidate solves/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'{args.workload} {scene["y"].shape[0]}x{scene["y"].shape[1]} (BASELINE.json configs[1] stand-in: ellipses at the centres/areas of a '
-                               'reference BBBC039 regression CSV), all candidates of the image per step: connected atom subsets of size <= '
-                               f'{args.max_size} + cluster universes', 'candidates_per_step_per_gpu': len(fps), 'atoms': int(scene['atoms'].max()),
+                               f'reference BBBC039 regression CSV), {n_images} images per step in ONE launch, all candidates of every image: connected atom '
+                               f'subsets of size <= {args.max_size} + cluster universes',
+                   'images_per_step': n_images, 'candidates_per_image': len(fps1), 'candidates_per_step_per_gpu': len(fps), 'atoms_per_image': int(scene['atoms'].max()),
                    'median_N': int(np.median(recs['n_pixels'])), 'median_M': int(np.median(recs['n_deform'])),
-                   'parallelism': f'{world} x (1 process per GPU), candidates sharded by image replica, one RCCL gather per step' if world > 1 else 'single GPU',
-                   'steps_in_flight': nfl, 'wall_ms_per_image': single_ms},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
-                     'kernel': 'sdsm_k_solve (all three size classes of one launch)', 'kernel_ms': kern_ms, 'setup_kernel_ms': setup_ms,
-                     'algorithmic_bytes_per_launch': alg_bytes,
-                     'achieved_with_steps_in_flight': alg_bytes * world / (dt / args.steps) / 1e9 / world,   # same bytes over the time per step of the timed region (per GPU)
+                   'parallelism': f'{world} x (1 process per GPU), weak scaling: every rank solves its own images, one RCCL gather of records + masks per step'
+                                  if world > 1 else 'single GPU',
+                   'steps_in_flight': nfl, 'timed_regions_ms': region_ms, 'value_is': 'median over the timed regions'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+                     'traffic': measured_traffic(args.workload, n_images),
+                     'kernel': 'sdsm_k_solve (the size classes of one launch run concurrently; class 1 <128, 2560, 256 threads> does the work here)',
+                     'kernel_ms': kern_ms, 'setup_kernel_ms': float(np.mean(setup_ms)), 'algorithmic_bytes_per_launch': alg_bytes,
+                     'achieved_in_timed_region': alg_bytes / (dt / args.steps) / 1e9,
                      'fp64_vector_tflops': flops / (kern_ms * 1e-3) / 1e12, 'fp64_vector_frac_of_78.6': flops / (kern_ms * 1e-3) / 1e12 / 78.6,
-                     'pixel_evaluations_per_launch': int((evals * recs['n_pixels']).sum())},
+                     'pixel_evaluations_per_launch': int((evals * recs['n_pixels']).sum()),
+                     'pixel_evaluations_per_image': int((evals * recs['n_pixels']).sum() // n_images)},
         'status_counts': {str(k): int(v) for k, v in zip(*np.unique(recs['status'], return_counts=True))},
     }
+    if rank == 0 and world == 1 and not args.no_extras:
+        out['extras'] = extras(args, scene, imgs[0], n_images)
     if rank == 0 and not args.no_cpu and world == 1:
-        out['cpu_baseline'] = cpu_baseline(scene, args.cpu_seconds)
+        out['cpu_baseline'] = cpu_baseline(scene, n_images, args.cpu_seconds)
+        if 'extras' in out and args.workload in ('bbbc039_like', 'synthetic256'):
+            ms, ncomp = cpu_stage_wall(scene, 150.0, 'isbi24')
+            out['extras']['stage_wall_ms_per_image_cpu_oracle'] = ms
+            out['extras']['stage_candidates_per_image'] = ncomp
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
         print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extras(args, scene, img, n_images):
+    """What BASELINE.json's metric names beside the solver throughput: wall clock per image through the product entry points."""
+    import torch
+    from superdsm_amd import config, engine, globalenergymin, image, objects
+    ex = {}
+    # (1) one image alone, one launch (latency scheduling), device only
+    lat = engine.Batch(img, scene['footprints'], scene['dsm_cfg'], latency_mode=True)
+    lat.launch()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        lat.launch()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t1) * 1e3)
+    ex['single_image_launch_ms'] = float(np.median(ts))
+    # (2) the reference-signature operator: plan + upload + launch + download + fragments + in-place results
+    yi = image.Image.create_from_array(scene['y'], normalize=False)
+    ts = []
+    for _ in range(4):
+        objs = [objects.Object() for _ in scene['footprints']]
+        for o, fp in zip(objs, scene['footprints']):
+            o.footprint = set(fp)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        objects.compute_objects(objs, yi, scene['atoms'], scene['dsm_cfg'], None, out='muted')
+        ts.append((time.perf_counter() - t1) * 1e3)
+    ex['compute_objects_wall_ms'] = float(np.median(ts[1:]))
+    ex['compute_objects_candidates'] = len(scene['footprints'])
+    # (3) the stage: all generations, host set cover, downloads -- wall clock per image, alone and 8 images in lock step
+    beta, pruning = 150.0, 'isbi24'
+    if args.workload in ('bbbc039_like', 'synthetic256'):
+        stage = globalenergymin.GlobalEnergyMinimization()
+        cfg = config.Config({'global-energy-minimization': {'beta': beta, 'pruning': pruning}})
+        mk = lambda: dict(y=scene['y'], y_mask=np.ones(scene['y'].shape, bool), atoms=scene['atoms'], adjacencies=scene['adjacencies'], dsm_cfg=scene['dsm_cfg'])
+        stage(mk(), cfg, out='muted')
+        ts = []
+        for _ in range(3):
+            d = mk()
+            t1 = time.perf_counter()
+            stage(d, cfg, out='muted')
+            ts.append((time.perf_counter() - t1) * 1e3)
+        ex['stage_wall_ms_per_image'] = float(np.median(ts))
+        ds = [mk() for _ in range(n_images)]
+        t1 = time.perf_counter()
+        stage.process_many(ds, cfg, out='muted')
+        ex[f'stage_wall_ms_per_image_lockstep{n_images}'] = (time.perf_counter() - t1) * 1e3 / n_images
+        ex['stage_pruning'] = pruning
+        ex['stage_beta'] = beta
+    # (4) preprocessing: 16 B / pixel algorithmic (read g, write y)
+    rng = np.random.default_rng(0)
+    pre = {}
+    for shape, sigma2 in (((520, 696), 10.0), ((4096, 4096), 10.0)):
+        g = torch.as_tensor(rng.random(shape)).cuda()
+        for _ in range(2):
+            engine.preprocess(g, sigma2=sigma2, return_tensor=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            engine.preprocess(g, sigma2=sigma2, return_tensor=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / reps * 1e3
+        px = shape[0] * shape[1]
+        pre[f'{shape[0]}x{shape[1]}'] = dict(ms=ms, algorithmic_GBps=16 * px / (ms * 1e-3) / 1e9, frac_of_8TBps=16 * px / (ms * 1e-3) / 8e12)
+    ex['preprocess'] = pre
+    return ex
+
+
+def image_set_mode(args, world, rank, backend):
+    """BASELINE.json configs[3]: a set of NIH3T3-like images dealt to the ranks; every rank runs the stage on its images in lock step,
+    ONE gather of the per-image results (cover footprints, energies) at the end.  value = candidate solves / s over the whole set."""
+    import torch
+    import torch.distributed as dist
+    from superdsm_amd import config, globalenergymin, testing
+    from superdsm_amd import dist as sdist
+    wl = args.workload if args.workload != 'bbbc039_like' else 'nih3t3_like'
+    scene = testing.make_scene(wl, max_size=2)
+    n_images = (args.images or 4) * world
+    mine = sdist.deal_images(n_images, world)[rank]
+    beta = {'nih3t3_like': 1200.0, 'gowt1_like': 1188.0}.get(wl, 150.0)
+    stage = globalenergymin.GlobalEnergyMinimization()
+    cfg = config.Config({'global-energy-minimization': {'beta': beta, 'pruning': 'isbi24'}})
+    mk = lambda i: dict(y=np.ascontiguousarray(scene['y'] * (1 - 0.003 * (i % 7))), y_mask=np.ones(scene['y'].shape, bool), atoms=scene['atoms'],
+                        adjacencies=scene['adjacencies'], dsm_cfg=scene['dsm_cfg'])
+    stage.process_many([mk(i) for i in mine[:1]], cfg, out='muted')            # warm-up: one image
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(max(1, min(args.repeats, 3))):
+        datas = [mk(i) for i in mine]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stage.process_many(datas, cfg, out='muted')
+        local = [(i, sorted(sorted(int(a) for a in o.footprint) for o in d['cover'].solution), float(d['cover'].costs),
+                  int(d['performance'].overall_computed_object_count)) for i, d in zip(mine, datas)]
+        got = sdist.gather_objects(local, dst=0) if world > 1 else [local]   # the one gather of the run
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        times.append(dt)
+    if rank == 0:
+        dt = float(np.median(times))
+        flat = sorted(x for part in got for x in part)
+        ncand = sum(x[3] for x in flat)
+        print(json.dumps({
+            'metric': 'candidate DSM solves/sec', 'value': ncand / dt, 'unit': 'candidate solves/s', 'n_gpus': world, 'steps': 1, 'warmup': 1,
+            'ms_per_step': dt * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'{wl} image set (BASELINE.json configs[3] stand-in): {n_images} images of {scene["y"].shape[0]}x{scene["y"].shape[1]}, '
+                                   f'{n_images // world} per GPU, global-energy-minimisation stage in lock step, one gather of the results at the end',
+                       'images': n_images, 'candidates_solved': ncand, 'wall_ms_per_image': dt * 1e3 / (n_images // world), 'objects_in_covers': sum(len(x[1]) for x in flat)},
+            'roofline': None, 'cpu_baseline': None}))
     if world > 1:
         dist.destroy_process_group()
 

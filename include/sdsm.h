@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SDSM_VERSION 100
+#define SDSM_VERSION 200
 
 typedef enum {
     SDSM_OK = 0,
@@ -82,7 +82,10 @@ typedef enum {
     SDSM_CAND_FALLBACK = 1,     /* DSM solve failed, elliptical result returned (objects.py:406-410) */
     SDSM_CAND_TRIVIAL = 2,      /* single positive pixel (objects.py:184-191): energy 0, is_optimal False */
     SDSM_CAND_ERROR = 3,        /* CvxprogError (objects.py:351-353) or malformed G~ (dsm.py:194) */
-    SDSM_CAND_UNSUPPORTED = 4   /* exceeds an implementation limit; elliptical result returned */
+    SDSM_CAND_UNSUPPORTED = 4,  /* exceeds an implementation limit; elliptical result returned */
+    SDSM_CAND_GIVEN_UP = 5      /* scheduling, not arithmetic: the workgroup group of a very large region waited too long for a member (GPU
+                                   oversubscribed by other work) and gave the candidate up; no result.  Solve it again with groups
+                                   disabled (sdsm_plan_set_latency_mode(plan, 2)); superdsm_amd.objects.compute_objects does. */
 } sdsm_cand_status;
 
 /* Per-atom statistics written by sdsm_image_prepare: for label l (1..n_atoms) six int32 at [6*l]:
@@ -122,6 +125,12 @@ typedef struct sdsm_plan sdsm_plan;   /* host-side plan: offsets into the worksp
 /* atom_stats: HOST copy of d_atom_stats.  offsets[n+1]/labels[]: footprints in CSR form (objects.py:53). */
 sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t *atom_stats, const sdsm_dsm_config *cfg,
                             int n, const int32_t *offsets, const int32_t *labels);
+/* The same for candidates of SEVERAL images in one plan (1 <= n_images <= 16): one launch then fills the GPU even when the batches
+ * of the single images are small (the generations of globalenergymin.py:228-263 are tens of candidates; an image set as in
+ * examples/NIH3T3).  H / W / n_atoms / atom_stats: one entry per image; image_of[i]: the image of candidate i (NULL: all 0); the
+ * labels of a footprint refer to that image's atoms.  All images share the hyper-parameters. */
+sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, const int32_t *W, const int32_t *n_atoms, const int32_t *const *atom_stats,
+                                  const sdsm_dsm_config *cfg, int n, const int32_t *offsets, const int32_t *labels, const int32_t *image_of);
 void sdsm_plan_destroy(sdsm_plan *plan);
 size_t sdsm_plan_workspace_bytes(const sdsm_plan *plan);
 size_t sdsm_plan_mask_bytes(const sdsm_plan *plan);       /* total size of the bit-packed region-bbox masks */
@@ -139,6 +148,9 @@ int sdsm_batch_upload(const sdsm_plan *plan, void *d_workspace, size_t workspace
 int sdsm_batch_launch(const sdsm_plan *plan, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid,
                       void *d_workspace, size_t workspace_bytes, sdsm_record *d_records, uint32_t *d_masks,
                       double *d_xi, void *stream);
+/* d_y / d_atoms / d_valid: HOST arrays of n_images device pointers (plans of sdsm_plan_create_multi). */
+int sdsm_batch_launch_multi(const sdsm_plan *plan, const double *const *d_y, const int32_t *const *d_atoms, const uint8_t *const *d_valid,
+                            void *d_workspace, size_t workspace_bytes, sdsm_record *d_records, uint32_t *d_masks, double *d_xi, void *stream);
 int64_t sdsm_plan_xi_count(const sdsm_plan *plan);
 /* Workspace layout for inspection (parity tests of the crops / grid / G~ rows).  out[16], byte offsets into the
  * workspace: 0 cand table, 1 cand state (M, status, ...), 2 crop_y f64, 3 crop_rc u32, 4 crop_cc u32 (setup order),
@@ -147,14 +159,25 @@ int64_t sdsm_plan_xi_count(const sdsm_plan *plan);
  * 15 reserved.  Candidate i's blocks start at crop offset sum(n_pixels[:i]), G~ offset that * zcap -- entry s of crop
  * position p at element ((s / 4) * N + p) * 4 + s % 4 of the candidate's block -- and grid offset xi_offset[i]. */
 int sdsm_plan_layout(const sdsm_plan *plan, int64_t *out);
-/* Scheduling of one batch.  Throughput mode (default): every candidate whose system fits is solved by a 256-thread
- * workgroup, two per compute unit -- most candidate solves per second when several batches are in flight.  Latency mode
- * (on = 1): regions of more than 3072 pixels are solved by a group of 2-4 cooperating 512-thread workgroups (a compute
- * unit each), which shortens the slowest candidates and with them the wall clock of a single batch (the reference waits for all candidates of an
- * image before the set-cover step, globalenergymin.py:131-137).  Results do not depend on the mode.  Changes the workspace size:
- * call it right after sdsm_plan_create, before sdsm_plan_workspace_bytes. */
-int sdsm_plan_set_latency_mode(sdsm_plan *plan, int on);
+/* Scheduling of one batch, mode =
+ *   0  throughput (default): every candidate whose system fits is solved by a 256-thread workgroup, two per compute unit -- most
+ *      candidate solves per second when the GPU is full (plans over several images, several batches in flight); only regions of
+ *      more than 12288 pixels are solved by a GROUP of cooperating 512-thread workgroups;
+ *   1  latency: regions of more than 3072 pixels are solved by groups of 2-4 workgroups too, which shortens the slowest candidates
+ *      and with them the wall clock of a single batch (the reference waits for all candidates of an image before the set-cover
+ *      step, globalenergymin.py:131-137);
+ *   2  no groups: every candidate by a single workgroup (slow for very large regions; the way to solve candidates again whose
+ *      group was given up, SDSM_CAND_GIVEN_UP).
+ * Results do not depend on the mode.  It changes the launch lists and the workspace size: call it before
+ * sdsm_plan_workspace_bytes / sdsm_batch_upload; a launch on a workspace uploaded before the change fails with SDSM_ERR_ARGUMENT. */
+int sdsm_plan_set_latency_mode(sdsm_plan *plan, int mode);
 int sdsm_plan_xi_offsets(const sdsm_plan *plan, int64_t *xi_offset);
+
+/* Host helper (no device access): the foreground fragments (objects.py:148-174) of a batch out of the downloaded records and
+ * bit-packed masks, one byte per pixel: fragment i (fg_h x fg_w, row-major) at out + out_offset[i]; candidates without a
+ * foreground get the single byte 0 ([[False]], objects.py:172-174).  Returns the bytes written -- or needed, when out == NULL. */
+int64_t sdsm_unpack_fragments(const sdsm_record *records, const int32_t *mask_info, const int64_t *mask_offset, const uint8_t *masks,
+                              int n, uint8_t *out, int64_t *out_offset);
 
 /* Parity / debug: psi, its gradient and the polynomial (theta) block of its Hessian at caller-given parameters, computed
  * by the evaluators of the solve kernels (Energy.__call__ / grad / hessian, superdsm/dsm.py:312-385) on the crops and G~
@@ -175,6 +198,9 @@ double sdsm_last_setup_kernel_ms(void);
 /* Diagnostic builds only (-DSDSM_PROFILE): device buffer receiving 8 int64 cycle counters per candidate
  * (phase A, phase B, reductions, factor+solve, line search, total, elliptical total, reserved). */
 int sdsm_set_debug_buffer(void *d_buf);
+/* Diagnostic: microseconds a member of a workgroup group waits for its partners before the group gives its candidate up
+ * (SDSM_CAND_GIVEN_UP); <= 0 restores the default of 10 s.  Applies to the launches of the calling thread. */
+int sdsm_set_group_timeout_us(double us);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,7 @@ def lib():
         L.orc_cvxprog.restype = vp
         L.orc_compute_objects.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, f64, C.POINTER(DsmCfg), i32]
         L.orc_compute_objects.restype = vp
+        L.orc_set_inner_threads.argtypes = [i32]
         L.orc_batch_free.argtypes = [vp]
         L.orc_batch_records.argtypes = [vp]
         L.orc_batch_records.restype = vp
@@ -237,8 +238,9 @@ def cvxprog(y, mask, dsm_cfg):
     return params[:6 + info.M].copy(), out
 
 
-def compute_objects(y, y_mask, atoms, footprints, dsm_cfg, nthreads=0):
-    """Returns (records structured array, list of bool fragments, list of parameter vectors)."""
+def compute_objects(y, y_mask, atoms, footprints, dsm_cfg, nthreads=0, inner_threads=1):
+    """Returns (records structured array, list of bool fragments, list of parameter vectors).  nthreads: worker threads (one
+    candidate each; 0 = all cores); inner_threads: threads per candidate (the passes over its pixels are split)."""
     y = _f64(y)
     atoms = np.ascontiguousarray(atoms, np.int32)
     ym = _u8(y_mask) if y_mask is not None else None
@@ -247,6 +249,7 @@ def compute_objects(y, y_mask, atoms, footprints, dsm_cfg, nthreads=0):
     labels = np.ascontiguousarray(np.concatenate([sorted(fp) for fp in footprints]) if len(footprints) else np.zeros(0), np.int32)
     cfg = DsmCfg.from_dict(dsm_cfg)
     L = lib()
+    L.orc_set_inner_threads(int(inner_threads))
     b = L.orc_compute_objects(_p(y), _p(ym) if ym is not None else None, _p(atoms), y.shape[0], y.shape[1], len(footprints),
                               _p(offs), _p(labels), float(dsm_cfg.get('background_margin', 20)), C.byref(cfg), int(nthreads))
     n = len(footprints)
@@ -259,6 +262,7 @@ def compute_objects(y, y_mask, atoms, footprints, dsm_cfg, nthreads=0):
         pp = L.orc_batch_params(b, i)
         params.append(np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_double)), shape=(6 + recs['M'][i],)).copy() if pp else None)
     L.orc_batch_free(b)
+    L.orc_set_inner_threads(1)
     return recs, frags, params
 
 

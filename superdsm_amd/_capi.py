@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('SDSM_HIP_LIB', os.path.join(_HERE, 'libsdsm_hip.so'))
 SDSM_OK = 0
 ATOM_STATS_STRIDE = 6
 
-CAND_OPTIMAL, CAND_FALLBACK, CAND_TRIVIAL, CAND_ERROR, CAND_UNSUPPORTED = 0, 1, 2, 3, 4
+CAND_OPTIMAL, CAND_FALLBACK, CAND_TRIVIAL, CAND_ERROR, CAND_UNSUPPORTED, CAND_GIVEN_UP = 0, 1, 2, 3, 4, 5
 
 
 class DsmConfig(C.Structure):
@@ -46,6 +46,7 @@ SYMBOLS = {
     'sdsm_image_workspace_bytes': (_sz, [_i32, _i32]),
     'sdsm_image_prepare': (_i32, [_vp, _vp, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _sz, _vp]),
     'sdsm_plan_create': (_vp, [_i32, _i32, _i32, _vp, C.POINTER(DsmConfig), _i32, _vp, _vp]),
+    'sdsm_plan_create_multi': (_vp, [_i32, _vp, _vp, _vp, _vp, C.POINTER(DsmConfig), _i32, _vp, _vp, _vp]),
     'sdsm_plan_destroy': (None, [_vp]),
     'sdsm_plan_workspace_bytes': (_sz, [_vp]),
     'sdsm_plan_mask_bytes': (_sz, [_vp]),
@@ -53,10 +54,12 @@ SYMBOLS = {
     'sdsm_plan_total_pixels': (_i64, [_vp]),
     'sdsm_batch_upload': (_i32, [_vp, _vp, _sz, _vp]),
     'sdsm_batch_launch': (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    'sdsm_batch_launch_multi': (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     'sdsm_plan_xi_count': (_i64, [_vp]),
     'sdsm_plan_xi_offsets': (_i32, [_vp, _vp]),
     'sdsm_plan_layout': (_i32, [_vp, _vp]),
     'sdsm_plan_set_latency_mode': (_i32, [_vp, _i32]),
+    'sdsm_unpack_fragments': (_i64, [_vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     'sdsm_plan_eval_param_count': (_i64, [_vp]),
     'sdsm_plan_eval_out_count': (_i64, [_vp]),
     'sdsm_batch_eval': (_i32, [_vp, _vp, _sz, _vp, _vp, _vp]),
@@ -64,6 +67,7 @@ SYMBOLS = {
     'sdsm_last_solve_kernel_ms': (_f64, []),
     'sdsm_last_setup_kernel_ms': (_f64, []),
     'sdsm_set_debug_buffer': (_i32, [_vp]),
+    'sdsm_set_group_timeout_us': (_i32, [_f64]),
 }
 
 _lib = None
@@ -87,7 +91,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        assert L.sdsm_version() >= 100
+        assert L.sdsm_version() >= 200
         _lib = L
     return _lib
 

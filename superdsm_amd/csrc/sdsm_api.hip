@@ -17,8 +17,7 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
-extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream,
-                                        const int32_t *order_w, int n_w);
+extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -112,20 +111,32 @@ extern "C" int sdsm_image_prepare(const double *d_y, const uint8_t *d_y_mask, co
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
+struct PlanImage { int H, W, n_atoms; };
 struct sdsm_plan {
-    int n = 0, H = 0, W = 0, n_atoms = 0;
+    int n = 0;
+    std::vector<PlanImage> images;             // one entry for sdsm_plan_create, several for sdsm_plan_create_multi
     sdsm_dsm_config cfg{};
     int k = 1, R = 0, zcap = 1, no_deform = 0;
     std::vector<CandDesc> cand;
     std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those whose bound on M admits more than solve class 1, then more than class 2
     int n_order_c = 0, n_order_d = 0, n_order_w = 0;   // the last list: (candidate | member << 24) of the workgroup groups
+    int mode = 0;                // sdsm_plan_set_latency_mode: 0 throughput, 1 latency, 2 no workgroup groups
     int wide_pixels = INT_MAX;   // throughput mode by default
     std::vector<float> psf;
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
     int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0, n_wide = 0;
     size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_ell_meta = 0,
-           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, total = 0;
+           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, off_ticket = 0, total = 0;
+    // The launch lists and CandDesc.wide_* live in the workspace (sdsm_batch_upload): a layout change after the upload
+    // (sdsm_plan_set_latency_mode) would leave stale tables on the device, so launches check the generation they were uploaded at.
+    uint64_t layout_gen = 0;
+    mutable uint64_t uploaded_gen = 0;
+    mutable const void *uploaded_ws = nullptr;
+    // side streams / fork-join events of the solve classes, owned by the plan (created at its first launch)
+    mutable bool sides_ready = false;
+    mutable hipStream_t side[2] = {nullptr, nullptr};
+    mutable hipEvent_t fj[3] = {nullptr, nullptr, nullptr};
 };
 
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -156,12 +167,14 @@ static uint32_t perm_inverse(uint32_t N)
 static void layout_plan(sdsm_plan *p)
 {
     const int n = p->n;
-    const bool latency = p->wide_pixels != INT_MAX;
+    const bool latency = p->mode == 1, groups = p->mode != 2;
+    p->wide_pixels = latency ? SDSM_WIDE_PIXELS : INT_MAX;
+    p->layout_gen++;
     p->n_wide = 0;
     for (int i = 0; i < n; i++) {
         CandDesc &c = p->cand[i];
         long G = 0;
-        if (n < (1 << 24)) {
+        if (groups && n < (1 << 24)) {
             if (c.N > SDSM_WIDE_MIN_PIXELS) G = std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (c.N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
             else if (latency && c.N > SDSM_WIDE_PIXELS) G = std::min<long>(SDSM_LAT_GMAX, std::max<long>(2, (c.N + SDSM_LAT_SLICE - 1) / SDSM_LAT_SLICE));   // latency mode: the largest regions of an ordinary image too
         }
@@ -204,18 +217,23 @@ static void layout_plan(sdsm_plan *p)
     p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1));      // n_hglob counts doubles
     p->off_wide = take(8 * (size_t)std::max<int64_t>(p->n_wide, 1));        // n_wide counts doubles
+    p->off_ticket = take(256);
     p->total = o;
 }
-extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t *atom_stats, const sdsm_dsm_config *cfg,
-                                       int n, const int32_t *offsets, const int32_t *labels)
+extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, const int32_t *W, const int32_t *n_atoms, const int32_t *const *atom_stats,
+                                             const sdsm_dsm_config *cfg, int n, const int32_t *offsets, const int32_t *labels, const int32_t *image_of)
 {
-    if (!atom_stats || !cfg || n < 0 || (n > 0 && (!offsets || !labels)) || H < 2 || W < 2) { fail(SDSM_ERR_ARGUMENT, "sdsm_plan_create: bad argument"); return nullptr; }
+    if (n_images < 1 || n_images > SDSM_MAX_IMAGES || !H || !W || !n_atoms || !atom_stats || !cfg || n < 0 || (n > 0 && (!offsets || !labels)) || (n > 0 && n_images > 1 && !image_of)) {
+        fail(SDSM_ERR_ARGUMENT, "sdsm_plan_create: bad argument (1 .. 16 images per plan)"); return nullptr;
+    }
+    for (int i = 0; i < n_images; i++) if (H[i] < 2 || W[i] < 2 || !atom_stats[i] || n_atoms[i] < 0) { fail(SDSM_ERR_ARGUMENT, "sdsm_plan_create: bad image"); return nullptr; }
     if (!(cfg->epsilon > 0) || !(cfg->alpha >= 0) || !(cfg->scale > 0) || cfg->smooth_subsample < 1 || !(cfg->smooth_amount > 0)) {
         fail(SDSM_ERR_ARGUMENT, "sdsm_plan_create: epsilon > 0, alpha >= 0, scale > 0, smooth_subsample >= 1, smooth_amount > 0 required (dsm.py:275-285)");
         return nullptr;
     }
     sdsm_plan *p = new sdsm_plan();
-    p->n = n; p->H = H; p->W = W; p->n_atoms = n_atoms; p->cfg = *cfg;
+    p->n = n; p->cfg = *cfg;
+    for (int i = 0; i < n_images; i++) p->images.push_back({H[i], W[i], n_atoms[i]});
     if (p->cfg.max_iters <= 0) p->cfg.max_iters = 100;
     p->no_deform = std::isinf(cfg->smooth_amount) ? 1 : 0;
     if (!p->no_deform) {
@@ -234,16 +252,20 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     p->fp_labels.assign(labels, labels + (n > 0 ? offsets[n] : 0));
     for (int i = 0; i < n; i++) {
         CandDesc &c = p->cand[i];
-        long N = 0; int r0 = H, r1 = -1, c0 = W, c1 = -1;
+        const int im = image_of ? image_of[i] : 0;
+        if (im < 0 || im >= n_images) { fail(SDSM_ERR_ARGUMENT, "sdsm_plan_create: image index out of range"); delete p; return nullptr; }
+        const int Hi = H[im], Wi = W[im];
+        long N = 0; int r0 = Hi, r1 = -1, c0 = Wi, c1 = -1;
         for (int e = offsets[i]; e < offsets[i + 1]; e++) {
             int l = labels[e];
-            if (l < 1 || l > n_atoms) continue;
-            const int32_t *st = atom_stats + (size_t)l * SDSM_ATOM_STATS_STRIDE;
+            if (l < 1 || l > n_atoms[im]) continue;
+            const int32_t *st = atom_stats[im] + (size_t)l * SDSM_ATOM_STATS_STRIDE;
             if (st[0] <= 0) continue;
             N += st[0];
             r0 = std::min(r0, st[1]); r1 = std::max(r1, st[2]); c0 = std::min(c0, st[3]); c1 = std::max(c1, st[4]);
         }
         if (r1 < 0) { r0 = c0 = 0; r1 = c1 = 0; N = 0; }
+        c.image = im; c.pad0 = 0;
         c.N = (int32_t)N; c.r0 = r0; c.c0 = c0; c.h = r1 - r0 + 1; c.w = c1 - c0 + 1;
         c.fp_off = offsets[i]; c.fp_len = offsets[i + 1] - offsets[i];
         long mc = p->no_deform ? 1 : (long)((c.h + s - 1) / s) * ((c.w + s - 1) / s);
@@ -264,12 +286,28 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
     return p;
 }
 
-extern "C" void sdsm_plan_destroy(sdsm_plan *plan) { delete plan; }
+extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t *atom_stats, const sdsm_dsm_config *cfg,
+                                       int n, const int32_t *offsets, const int32_t *labels)
+{
+    const int32_t h = H, w = W, na = n_atoms;
+    return sdsm_plan_create_multi(1, &h, &w, &na, &atom_stats, cfg, n, offsets, labels, nullptr);
+}
+
+extern "C" void sdsm_plan_destroy(sdsm_plan *plan)
+{
+    if (!plan) return;
+    if (plan->sides_ready) {
+        for (int i = 0; i < 2; i++) if (plan->side[i]) (void)hipStreamDestroy(plan->side[i]);
+        for (int i = 0; i < 3; i++) if (plan->fj[i]) (void)hipEventDestroy(plan->fj[i]);
+    }
+    delete plan;
+}
 extern "C" int sdsm_plan_set_latency_mode(sdsm_plan *p, int on)
 {
     if (!p) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_set_latency_mode: null plan");
-    p->wide_pixels = on ? SDSM_WIDE_PIXELS : INT_MAX;
-    layout_plan(p);                                       // changes the workspace size: call before sdsm_plan_workspace_bytes
+    if (on < 0 || on > 2) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_set_latency_mode: mode must be 0, 1 or 2");
+    p->mode = on;
+    layout_plan(p);                                       // new launch lists / workspace size / generation: upload again before the next launch
     return SDSM_OK;
 }
 extern "C" size_t sdsm_plan_workspace_bytes(const sdsm_plan *p) { return p ? p->total : 0; }
@@ -307,7 +345,7 @@ extern "C" int sdsm_batch_upload(const sdsm_plan *p, void *d_ws, size_t ws_bytes
 {
     if (!p || !d_ws) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_upload: null argument");
     if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_upload: workspace too small");
-    if (p->n == 0) return SDSM_OK;
+    if (p->n == 0) { p->uploaded_gen = p->layout_gen; p->uploaded_ws = d_ws; return SDSM_OK; }
     uint8_t *b = (uint8_t *)d_ws;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
@@ -315,10 +353,14 @@ extern "C" int sdsm_batch_upload(const sdsm_plan *p, void *d_ws, size_t ws_bytes
     if (!p->fp_labels.empty() && (e = hipMemcpyAsync(b + p->off_fp, p->fp_labels.data(), 4 * p->fp_labels.size(), hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload footprints");
     if ((e = hipMemcpyAsync(b + p->off_order, p->order.data(), 4 * p->order.size(), hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload order");
     if ((e = hipMemcpyAsync(b + p->off_psf, p->psf.data(), 4 * p->psf.size(), hipMemcpyHostToDevice, s)) != hipSuccess) return hipfail(e, "upload psf");
+    p->uploaded_gen = p->layout_gen; p->uploaded_ws = d_ws;
     return SDSM_OK;
 }
 
 static thread_local long long *g_prof = nullptr;
+static thread_local long long g_wide_timeout = 1000000000ll;   // ticks of the 100 MHz wall clock: 10 s
+// Diagnostic: time a member of a workgroup group waits for its partners before the group is given up (default 1e7 us).
+extern "C" int sdsm_set_group_timeout_us(double us) { g_wide_timeout = us > 0 ? (long long)(us * 100.0) : 1000000000ll; return SDSM_OK; }
 // Diagnostic builds (-DSDSM_PROFILE): device buffer of 8 int64 cycle counters per candidate, see DESIGN.md.
 extern "C" int sdsm_set_debug_buffer(void *d_buf) { g_prof = (long long *)d_buf; return SDSM_OK; }
 
@@ -331,7 +373,8 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
 {
     uint8_t *b = (uint8_t *)d_ws;
     BatchParams P{};
-    P.n = p->n; P.H = p->H; P.W = p->W; P.n_atoms = p->n_atoms;
+    P.n = p->n; P.n_images = (int)p->images.size();
+    for (size_t i = 0; i < p->images.size(); i++) { P.img[i].H = p->images[i].H; P.img[i].W = p->images[i].W; }   // device pointers: filled by the launch
     P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
     P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels;
     P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
@@ -345,14 +388,10 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
     P.psf = (const float *)(b + p->off_psf);
     P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
     P.hglob = (double *)(b + p->off_hglob); P.wide_pool = (double *)(b + p->off_wide);
+    P.wide_ticket = (int32_t *)(b + p->off_ticket); P.wide_timeout = g_wide_timeout;
     P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
     return P;
 }
-
-// side streams / fork-join events of the three solve classes: one set per caller stream (created on first use, per
-// host thread), so that batches queued on different streams overlap instead of serialising on shared side streams
-struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; };
-static thread_local std::vector<std::pair<hipStream_t, SideSet>> g_sides;
 
 static thread_local int g_timing = 0;
 static thread_local hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
@@ -378,30 +417,37 @@ static double elapsed(int a, int b)
 extern "C" double sdsm_last_setup_kernel_ms(void) { return elapsed(0, 1); }
 extern "C" double sdsm_last_solve_kernel_ms(void) { return elapsed(1, 2); }
 
+extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *d_y, const int32_t *const *d_atoms, const uint8_t *const *d_valid,
+                                       void *d_ws, size_t ws_bytes, sdsm_record *d_records, uint32_t *d_masks, double *d_xi, void *stream)
+{
+    if (!p || !d_y || !d_atoms || !d_valid || !d_ws || !d_records || !d_masks) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: null argument");
+    for (size_t i = 0; i < p->images.size(); i++) if (!d_y[i] || !d_atoms[i] || !d_valid[i]) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: null image pointer");
+    if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_launch: workspace too small");
+    if (p->uploaded_gen != p->layout_gen || p->uploaded_ws != d_ws)
+        return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: the plan's tables in this workspace are missing or stale (sdsm_batch_upload must follow sdsm_plan_create and every sdsm_plan_set_latency_mode)");
+    if (p->n == 0) return SDSM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    BatchParams P = make_params(p, d_ws);
+    for (size_t i = 0; i < p->images.size(); i++) { P.img[i].y = d_y[i]; P.img[i].atoms = d_atoms[i]; P.img[i].valid = d_valid[i]; }
+    hipError_t e;
+    if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
+    if ((e = sdsm_launch_setup(P, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch setup");
+    if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
+    if (!p->sides_ready && (p->n_order_c > 0 || p->n_order_d > 0 || p->n_order_w > 0)) {
+        for (int i = 0; i < 2; i++) if ((e = hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
+        for (int i = 0; i < 3; i++) if ((e = hipEventCreateWithFlags(&p->fj[i], hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
+        p->sides_ready = true;
+    }
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, p->side[0], p->side[1], nullptr, const_cast<hipEvent_t *>(p->fj), p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
+    if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
+    return SDSM_OK;
+}
+
 extern "C" int sdsm_batch_launch(const sdsm_plan *p, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid,
                                  void *d_ws, size_t ws_bytes, sdsm_record *d_records, uint32_t *d_masks, double *d_xi, void *stream)
 {
-    if (!p || !d_y || !d_atoms || !d_valid || !d_ws || !d_records || !d_masks) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: null argument");
-    if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_launch: workspace too small");
-    if (p->n == 0) return SDSM_OK;
-    hipStream_t s = (hipStream_t)stream;
-    const BatchParams P = make_params(p, d_ws);
-    hipError_t e;
-    if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    if ((e = sdsm_launch_setup(P, (const double *)d_y, (const int32_t *)d_atoms, (const uint8_t *)d_valid, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch setup");
-    if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    SideSet *ss = nullptr;
-    for (auto &kv : g_sides) if (kv.first == s) ss = &kv.second;
-    if (!ss) {
-        SideSet n{};
-        for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithFlags(&n.side[i], hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
-        for (int i = 0; i < 4; i++) if ((e = hipEventCreateWithFlags(&n.fj[i], hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
-        g_sides.emplace_back(s, n);
-        ss = &g_sides.back().second;
-    }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, ss->side[0], ss->side[1], ss->side[2], ss->fj, p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
-    if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
-    return SDSM_OK;
+    if (p && p->images.size() != 1) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: the plan covers several images, use sdsm_batch_launch_multi");
+    return sdsm_batch_launch_multi(p, &d_y, &d_atoms, &d_valid, d_ws, ws_bytes, d_records, d_masks, d_xi, stream);
 }
 
 // ---- point evaluation for parity tests ---------------------------------------------------------------------
@@ -419,7 +465,38 @@ extern "C" int sdsm_batch_eval(const sdsm_plan *p, void *d_ws, size_t ws_bytes, 
     hipError_t e;
     // results of candidates that cannot be evaluated (trivial, failed setup, beyond the solver's limits) stay NaN
     if ((e = hipMemsetAsync(d_out, 0xff, sizeof(double) * (size_t)sdsm_plan_eval_out_count(p), s)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
+    if (p->uploaded_gen != p->layout_gen || p->uploaded_ws != d_ws) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_eval: needs the workspace of a previous sdsm_batch_launch of this plan");
     const BatchParams P = make_params(p, d_ws);
     if ((e = sdsm_launch_eval(P, d_params, d_out, s)) != hipSuccess) return hipfail(e, "launch eval");
     return SDSM_OK;
+}
+
+// ---- host helper: foreground fragments out of the bit-packed masks (objects.py:148-174 applied to the region-bbox masks) -------
+// One byte per pixel of every fragment into `out` (fragment i: fg_h * fg_w bytes, row-major, at out_offset[i]); candidates
+// without a foreground (fg_h <= 0, trivial, failed) get the single byte 0 = [[False]] (objects.py:172-174, 185-186).
+// Returns the number of bytes written (or needed when out == NULL), < 0 on error.
+extern "C" int64_t sdsm_unpack_fragments(const sdsm_record *records, const int32_t *mask_info, const int64_t *mask_offset, const uint8_t *masks,
+                                         int n, uint8_t *out, int64_t *out_offset)
+{
+    if (n < 0 || (n > 0 && (!records || !mask_info || !mask_offset || !masks))) return fail(SDSM_ERR_ARGUMENT, "sdsm_unpack_fragments: null argument");
+    int64_t pos = 0;
+    for (int i = 0; i < n; i++) {
+        const sdsm_record &r = records[i];
+        const bool empty = r.fg_h <= 0 || r.status == SDSM_CAND_TRIVIAL || r.status == SDSM_CAND_ERROR || r.status == SDSM_CAND_GIVEN_UP;
+        if (out_offset) out_offset[i] = pos;
+        if (empty) { if (out) out[pos] = 0; pos += 1; continue; }
+        const int r0 = mask_info[4 * i], c0 = mask_info[4 * i + 1], h = mask_info[4 * i + 2], w = mask_info[4 * i + 3];
+        const int fr = r.fg_r0 - r0, fc = r.fg_c0 - c0;
+        if (fr < 0 || fc < 0 || fr + r.fg_h > h || fc + r.fg_w > w) return fail(SDSM_ERR_ARGUMENT, "sdsm_unpack_fragments: fragment outside its mask box");
+        if (out) {
+            const uint32_t *words = reinterpret_cast<const uint32_t *>(masks + mask_offset[i]);
+            uint8_t *o = out + pos;
+            for (int a = 0; a < r.fg_h; a++) {
+                int64_t bit = (int64_t)(fr + a) * w + fc;
+                for (int b = 0; b < r.fg_w; b++, bit++) *o++ = (uint8_t)((words[bit >> 5] >> (bit & 31)) & 1u);
+            }
+        }
+        pos += (int64_t)r.fg_h * r.fg_w;
+    }
+    return pos;
 }

@@ -69,6 +69,8 @@ struct CandDesc {
     int32_t wide_g;     // > 0: solved by a group of this many workgroups (regions of more than SDSM_WIDE_MIN_PIXELS pixels)
     int64_t hglob_off;  // first double of its block in the global Hessian pool (a dense triangle of 6 + min(Mcap, 1018) unknowns; only if 6 + Mcap > SDSM_ENV_DENSE_N: the envelope may not fit LDS), else -1
     int64_t wide_off;   // first double of the group's block in the wide pool: SDSM_WIDE_SYNC + 2 * wide_g * SDSM_WIDE_PBUF doubles; else -1
+    int32_t image;      // index into BatchParams.img (plans over several images, sdsm_plan_create_multi)
+    int32_t pad0;
 };
 
 // Written by the setup kernel.
@@ -86,10 +88,20 @@ struct CandState {
     int32_t gcount[8];  // gcount[j] = crop positions whose row has more than 4 j entries (positions are sorted by that)
 };
 static_assert(sizeof(CandState) == 104 && SDSM_ELL_GROUPS_REG <= 8, "CandState layout");
-static_assert(sizeof(CandDesc) == 88, "CandDesc layout");
+static_assert(sizeof(CandDesc) == 96, "CandDesc layout");
+
+// One image of a plan: device pointers given at launch time, shape from the plan.
+#define SDSM_MAX_IMAGES 16
+struct ImageRef {
+    const double *y;
+    const int32_t *atoms;
+    const uint8_t *valid;
+    int32_t H, W;
+};
 
 struct BatchParams {
-    int32_t n, H, W, n_atoms;
+    int32_t n, n_images;
+    ImageRef img[SDSM_MAX_IMAGES];
     int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, ELL slots per pixel (a multiple of 4)
     int32_t no_deform;                 // smooth_amount == inf
     int32_t no_trivial_rule;           // sdsm_dsm_config.flags bit 0: solve even a region with a single positive pixel (cvxprog called directly, c2freganal.py:58-79)
@@ -122,6 +134,8 @@ struct BatchParams {
     int32_t *env_rb;
     const float *psf;
     double *wide_pool;                 // sync words and all-reduce buffers of the workgroup groups (CandDesc.wide_off)
+    int32_t *wide_ticket;              // [0]: next entry of the group launch list (members are claimed in the order in which workgroups START, see sdsm_solve.hip)
+    long long wide_timeout;            // ticks of the 100 MHz wall clock a group member waits for its partners before the group is given up
     double *hglob;                     // Hessian pool of the global-memory class (envelope too large for LDS), CandDesc.hglob_off
     long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 16 cycle counters per candidate (solve kernel)
     long long *prof2;                  // diagnostic build only: 8 cycle counters per candidate (setup kernel), behind the 16 n solve counters

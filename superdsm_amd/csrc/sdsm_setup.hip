@@ -167,9 +167,7 @@ __device__ __forceinline__ int envelope_from_first(const BatchParams &P, const C
 
 }  // namespace
 
-__global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const double *__restrict__ y,
-                                                         const int32_t *__restrict__ atoms,
-                                                         const uint8_t *__restrict__ valid)
+__global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P)
 {
     // footprint bitset during the region scan (2048 words), then the PSF table (k * k floats, if it fits) for the rows of G~
     __shared__ uint32_t fp_or_psf[SDSM_PSF_LDS];
@@ -195,7 +193,12 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
     const int ci = P.order[blockIdx.x];
     const CandDesc cd = P.cand[ci];
     CandState *st = &P.state[ci];
+    const ImageRef im = P.img[cd.image];
+    const double *__restrict__ y = im.y;
+    const int32_t *__restrict__ atoms = im.atoms;
+    const uint8_t *__restrict__ valid = im.valid;
 
+    if (blockIdx.x == 0 && tid == 0) *P.wide_ticket = 0;
     if (cd.wide_g > 0 && tid < 2 * SDSM_WIDE_SYNC) reinterpret_cast<int *>(P.wide_pool + cd.wide_off)[tid] = 0;   // counters of the workgroup group
     if (cd.h > SDSM_MAX_BBOX_DIM || cd.w > SDSM_MAX_BBOX_DIM || cd.N <= 0) {
         if (tid == 0) { CandState s = {}; s.status = cd.N <= 0 ? ST_ERROR : ST_UNSUPPORTED; *st = s; }
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P, const dou
         double yv = 0;
         if (i < area) {
             r = i / cd.w; c = i - r * cd.w;
-            size_t p = (size_t)(cd.r0 + r) * P.W + (cd.c0 + c);
+            size_t p = (size_t)(cd.r0 + r) * im.W + (cd.c0 + c);
             int a = atoms[p];
             flag = a >= 1 && a <= SDSM_MAX_LABELS && ((fpbits[a >> 5] >> (a & 31)) & 1u) && valid[p];
             if (flag) yv = y[p];
@@ -551,10 +554,9 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
     }
 }
 
-extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, const double *d_y, const int32_t *d_atoms, const uint8_t *d_valid, hipStream_t stream,
-                                        const int32_t *order_w, int n_w)
+extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w)
 {
-    hipLaunchKernelGGL(sdsm_k_setup, dim3(P.n), dim3(SDSM_WG), 0, stream, P, d_y, d_atoms, d_valid);
+    hipLaunchKernelGGL(sdsm_k_setup, dim3(P.n), dim3(SDSM_WG), 0, stream, P);
     if (n_w > 0) {                                       // (candidate | member << 24) of the workgroup groups
         BatchParams Pw = P;
         Pw.order = order_w; Pw.n = n_w;

@@ -92,6 +92,7 @@ struct Cand {                       // per-candidate global pointers (already of
     int p_lo, p_hi;                     // the crop positions this workgroup covers in a pass (the whole crop unless it is one of a group)
     int wg, wG;                         // member index and size of the workgroup group (wG = 1: none)
     double *wpool;                      // the group's block of BatchParams.wide_pool
+    long long wtimeout;                 // BatchParams.wide_timeout
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
     double reg0;                        // alpha * sqrt(epsilon) * M: the regulariser's value at xi = 0 (dsm.py:325-326)
@@ -120,7 +121,7 @@ __device__ __forceinline__ CandDesc uniform_desc(const CandDesc &d)
     u.crop_off = uni((long long)d.crop_off); u.ell_off = uni((long long)d.ell_off); u.mask_off = uni((long long)d.mask_off); u.xi_off = uni((long long)d.xi_off);
     u.N = uni(d.N); u.r0 = uni(d.r0); u.c0 = uni(d.c0); u.h = uni(d.h); u.w = uni(d.w); u.fp_off = uni(d.fp_off); u.fp_len = uni(d.fp_len);
     u.Mcap = uni(d.Mcap); u.perm_inv = uni(d.perm_inv); u.wide_g = uni(d.wide_g);
-    u.hglob_off = uni((long long)d.hglob_off); u.wide_off = uni((long long)d.wide_off);
+    u.hglob_off = uni((long long)d.hglob_off); u.wide_off = uni((long long)d.wide_off); u.image = uni(d.image); u.pad0 = 0;
     return u;
 }
 __device__ __forceinline__ CandState uniform_state(const CandState &d)
@@ -141,7 +142,7 @@ __device__ __forceinline__ Cand uniform_cand(const Cand &c)
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) u.gcount[j] = uni(c.gcount[j]);
     u.hglob = (double *)uni((unsigned long long)c.hglob);
     u.N = uni(c.N); u.zmax = uni(c.zmax); u.hzmax = uni(c.hzmax); u.env_size = uni(c.env_size);
-    u.p_lo = uni(c.p_lo); u.p_hi = uni(c.p_hi); u.wg = uni(c.wg); u.wG = uni(c.wG); u.wpool = (double *)uni((unsigned long long)c.wpool);
+    u.p_lo = uni(c.p_lo); u.p_hi = uni(c.p_hi); u.wg = uni(c.wg); u.wG = uni(c.wG); u.wpool = (double *)uni((unsigned long long)c.wpool); u.wtimeout = uni(c.wtimeout);
     u.rmid = uni(c.rmid); u.cmid = uni(c.cmid); u.inv_hr = uni(c.inv_hr); u.inv_hc = uni(c.inv_hc);
     u.scale = uni(c.scale); u.epsilon = uni(c.epsilon); u.alpha = uni(c.alpha); u.reg0 = uni(c.reg0);
     return u;
@@ -169,7 +170,15 @@ template <class L> __device__ __forceinline__ double *hess_ptr(const Cand &c) { 
 // branches.  Barrier: a monotonic counter, arrival = agent-scope release add by one lane after the workgroup barrier,
 // wait = agent-scope acquire loads by that lane (the members sit on different XCDs, whose L2s are not coherent), with a
 // time limit: a member that waits longer than ~10 s flags the group and every member gives the candidate up (status
-// error) instead of hanging.  Two publication slots alternate: a member can be at most one all-reduce ahead.
+// SDSM_CAND_GIVEN_UP: the host solves it again without a group) instead of hanging.  Two publication slots alternate: a
+// member can be at most one all-reduce ahead.
+// Residency: a member is not bound to its workgroup index.  Every workgroup of the group launch draws a TICKET when it
+// starts (one atomic add on BatchParams.wide_ticket) and becomes entry `ticket` of the launch list, in which the members of
+// a group are consecutive.  Tickets are handed out in the order in which workgroups actually start, whatever that order is,
+// so at any time the running workgroups hold a dense prefix of the list: every group except at most the last one of the
+// prefix is complete and finishes on its own; the incomplete one holds fewer than its size (<= 8) compute units and gets
+// the next tickets as soon as any compute unit frees up.  K group launches in flight (streams, processes) can hold at most
+// 7 K compute units in incomplete groups, so with K < 36 on 256 compute units somebody always progresses.
 #define WIDE_PHASE (reinterpret_cast<int *>(SD + L::FLAG) + 2)   // all-reduces done so far (LDS, uniform)
 
 template <class L>
@@ -185,7 +194,7 @@ __device__ __forceinline__ bool wide_barrier(const Cand &c, int phase0)
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            if (wall_clock64() - t0 > 1000000000ll) { __hip_atomic_store(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // constant 100 MHz clock: 10 s
+            if (wall_clock64() - t0 > c.wtimeout) { __hip_atomic_store(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // constant 100 MHz clock; default 10 s
             __builtin_amdgcn_s_sleep(8);
         }
     }
@@ -302,7 +311,10 @@ __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, dou
     theta = bad ? t : theta;
     *phi = bad ? t : ph;
     *r = -yv * theta;
-    *dcurv = yv * yv * (theta - theta * theta);
+    // kappa = theta - theta^2 (dsm.py:361) = u / (1 + u)^2: the product form has no cancellation for theta -> 1 (the reference's
+    // difference loses all digits there: kappa < 1e-16 comes out as 0 or 1.1e-16)
+    const double kap = u * rw * rw;
+    *dcurv = yv * yv * (bad ? t : kap);
 }
 
 // Row of G~ for crop position p into registers.  Positions are sorted by row length (4-entry groups, longest first) and
@@ -1167,7 +1179,16 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 {
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
     int tid = threadIdx.x;                                   // re-derived (opaque_tid) at the start of every section: nothing per-thread is kept across the solver
-    const int entry = uni(P.order[blockIdx.x]);
+    int slot = blockIdx.x;
+    if (WIDE) {                                              // members are claimed in start order, not by workgroup index (see wide_barrier)
+        int *tk = reinterpret_cast<int *>(SD + L::FLAG);
+        if (tid == 0) *tk = __hip_atomic_fetch_add(P.wide_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        slot = uni(*tk);
+        __syncthreads();
+        if (slot >= P.n) return;                             // cannot happen: one ticket per workgroup of the launch
+    }
+    const int entry = uni(P.order[slot]);
     const int ci = WIDE ? entry & 0xffffff : entry;
     const int wg = WIDE ? (entry >> 24) & 0xff : 0;
     const CandDesc cd = uniform_desc(P.cand[ci]);
@@ -1203,7 +1224,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 
     Cand c;
     c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0; c.hzmax = Mfull > 0 ? st.hzmax : 0; c.env_size = 21;
-    c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr;
+    c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr; c.wtimeout = P.wide_timeout;
     if (WIDE) {
         c.wG = cd.wide_g; c.wg = wg; c.wpool = P.wide_pool + cd.wide_off;
         const int chunk = (((cd.N + c.wG - 1) / c.wG) + 63) & ~63;           // slices start at multiples of 64 (row-group logic of load_row)
@@ -1254,7 +1275,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
             r.flags |= 1;
             __syncthreads();
             if (tid == 0) {                                                     // one lane: the divisions and square roots of the moment model need many registers
-                const Frame fr = make_frame(c, P.H, P.W);
+                const Frame fr = make_frame(c, P.img[cd.image].H, P.img[cd.image].W);
                 const double z0 = fr.z0, z1 = fr.z1;
                 int q_n = st.npos;
                 unsigned long long q_r = st.sum_r, q_c = st.sum_c, q_rr = st.sum_rr, q_cc = st.sum_cc;
@@ -1360,13 +1381,14 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
             }
         }
         // 1-px pad ring of the image, polynomial part only (G~ has no rows there)
-        const int ringw = P.W + 2, ringh = P.H + 2;
+        const int imH = P.img[cd.image].H, imW = P.img[cd.image].W;
+        const int ringw = imW + 2, ringh = imH + 2;
         for (int i = tid; i < 2 * ringw + 2 * ringh; i += L::WGS) {
             int pr, pc;
             if (i < ringw) { pr = -1; pc = i - 1; }
-            else if (i < 2 * ringw) { pr = P.H; pc = i - ringw - 1; }
+            else if (i < 2 * ringw) { pr = imH; pc = i - ringw - 1; }
             else if (i < 2 * ringw + ringh) { pr = i - 2 * ringw - 1; pc = -1; }
-            else { pr = i - 2 * ringw - ringh - 1; pc = P.W; }
+            else { pr = i - 2 * ringw - ringh - 1; pc = imW; }
             double u = ((double)pr - c.rmid) * c.inv_hr, v = ((double)pc - c.cmid) * c.inv_hc;
             double Sv = u * u * x[0] + v * v * x[1] + 2 * (u * v) * x[2] + 2 * u * x[3] + 2 * v * x[4] + x[5];
             if (Sv > 0) onb = 1;
@@ -1387,18 +1409,18 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
             rmin = o[0] < rmin ? o[0] : rmin; cmin = o[1] < cmin ? o[1] : cmin;
             rmax = o[2] > rmax ? o[2] : rmax; cmax = o[3] > cmax ? o[3] : cmax;
         }
-        if (!okw) status_final = SDSM_CAND_ERROR;                            // the group was given up (a member waited too long)
+        if (!okw) status_final = SDSM_CAND_GIVEN_UP;                         // the group was given up (a member waited too long): not a solver failure
         if (c.wg != 0) return;                                               // member 0 writes the record
     }
 
     if (xi_out) for (int j = opaque_tid(); j < st.M; j += L::WGS) xi_out[cd.xi_off + j] = j < Mfull ? x[6 + j] : 0;
     if (tid == 0) {
         // local basis -> full-image-normalised theta:  u = (x0 - O0) / P0
-        const Frame fr = make_frame(c, P.H, P.W);
+        const Frame fr = make_frame(c, P.img[cd.image].H, P.img[cd.image].W);
         double thl[6] = {x[0], x[1], x[2], x[3], x[4], x[5]}, thg[6];
         reparam(thl, 1 / fr.P0, 1 / fr.P1, -fr.O0 / fr.P0, -fr.O1 / fr.P1, thg);
         for (int i = 0; i < 6; i++) r.theta[i] = thg[i];
-        r.energy = status_final == SDSM_CAND_ERROR ? NAN : psi_final;
+        r.energy = (status_final == SDSM_CAND_ERROR || status_final == SDSM_CAND_GIVEN_UP) ? NAN : psi_final;
         r.status = status_final;
         r.evals_value = ev_value; r.evals_full = ev_full;
         r.n_positive = st.npos; r.n_negative = st.nneg;
@@ -1437,7 +1459,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     if (GLOBALH && cd.hglob_off < 0) return;
     Cand c;
     c.N = cd.N; c.zmax = M > 0 ? st.zmax : 0; c.hzmax = M > 0 ? st.hzmax : 0; c.env_size = efull;
-    c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr;
+    c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr; c.wtimeout = 0;
     c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
     c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
 #pragma unroll
@@ -1447,7 +1469,8 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
     c.inv_hr = 1.0 / (half_r < 1 ? 1 : half_r); c.inv_hc = 1.0 / (half_c < 1 ? 1 : half_c);
-    const double z0 = P.H > 1 ? P.H - 1.0 : 1.0, z1 = P.W > 1 ? P.W - 1.0 : 1.0;
+    const int imH = P.img[cd.image].H, imW = P.img[cd.image].W;
+    const double z0 = imH > 1 ? imH - 1.0 : 1.0, z1 = imW > 1 ? imW - 1.0 : 1.0;
     const double P0 = 1.0 / (c.inv_hr * z0), P1 = 1.0 / (c.inv_hc * z1), O0 = c.rmid / z0, O1 = c.cmid / z1;
     c = uniform_cand(c);
     double *x = SD + L::X, *g = SD + L::G, *Hp = hess_ptr<L>(c);
@@ -1541,15 +1564,21 @@ static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int p
     auto kern = sdsm_k_solve<NMAX, EMAX, WPE, GLOBALH, WGSIZE, WIDE>;
     constexpr int lds = Lay<NMAX, EMAX, GLOBALH, WGSIZE>::TOTAL_BYTES;
     static_assert(lds <= 160 * 1024 - 512, "LDS budget");
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
+    static bool attr_set[64] = {};                       // per instantiation and device; the attribute belongs to the function, not to the launch
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
     if (P.n <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nprev, eprev, pixprev, pixmax, handles_rest, records, masks, xi_out);
     return hipGetLastError();
 }
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
-                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */,
+                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 3 */,
                                         int n_c, int n_d, int n_w)
 {
     hipError_t e;

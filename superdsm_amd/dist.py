@@ -24,13 +24,21 @@ def shard_indices(costs, world):
 class RecordGather:
     """Gathers every rank's record block and mask block to rank 0 (padded to the largest rank's size)."""
 
-    def __init__(self, batch_or_tensors, world, rank, group=None):
+    def __init__(self, batch_or_tensors, world, rank, group=None, sizes=None):
+        """sizes: (world, 2) array of every rank's (record bytes, mask bytes) when the caller knows them (replicated plans);
+        otherwise they are exchanged once, here -- never per batch."""
         if isinstance(batch_or_tensors, tuple):
             self.records, self.masks = batch_or_tensors
         else:
             self.records, self.masks = batch_or_tensors.records_dev, batch_or_tensors.masks_dev
         self.world, self.rank, self.group = world, rank, group
         dev = self.records.device
+        if sizes is not None:
+            self.sizes = np.asarray(sizes, np.int64).reshape(world, 2)
+            self.pad = int(self.sizes.sum(axis=1).max())
+            self.send = torch.zeros(self.pad, dtype=torch.uint8, device=dev)
+            self.recv = [torch.zeros(self.pad, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            return
         sizes = torch.tensor([self.records.numel(), self.masks.numel()], dtype=torch.int64, device=dev)
         all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
         if dist.get_backend(group) == 'gloo' and sizes.is_cuda:
@@ -71,41 +79,31 @@ class RecordGather:
         return out
 
 
-def _gpu_solve_local(image, footprints, cfg):
-    """Default local solver of a shard: one engine batch on this rank's GPU.  Returns (records bytes, mask_info
-    int32 [n,4], mask_offset int64 [n], masks bytes), all numpy."""
+def _gpu_solve_local(image, footprints, cfg, mask_info):
+    """Default local solver of a shard: one engine batch on this rank's GPU.  Returns (records, masks) as uint8 DEVICE tensors
+    (nothing is copied to the host here); ``mask_info`` is what every rank expects the shard's mask boxes to be."""
     from . import engine
     batch = engine.Batch(image, footprints, cfg, latency_mode=True)
+    assert np.array_equal(batch.mask_info[:len(footprints)], mask_info), 'plan of the shard disagrees with the replicated layout'
     batch.launch()
-    torch.cuda.synchronize(image.device)
     n = len(footprints)
-    return (batch.records_dev.cpu().numpy()[:n * 128].copy(), batch.mask_info[:n].copy(), batch.mask_offset[:n].copy(),
-            batch.masks_dev.cpu().numpy().copy())
+    return batch.records_dev[:n * 128], batch.masks_dev, batch          # (the batch keeps the buffers alive)
 
 
 def fragments_from_masks(records, mask_info, mask_offset, masks):
-    """Foreground fragments from bit-packed region-bbox masks (same rule as engine.Batch.fragments)."""
-    from . import _capi
-    out = []
-    for i, r in enumerate(records):
-        if r['fg_h'] <= 0 or r['status'] in (_capi.CAND_TRIVIAL, _capi.CAND_ERROR):
-            out.append((np.zeros(2, int), np.zeros((1, 1), bool)))
-            continue
-        r0, c0, h, w = (int(v) for v in mask_info[i])
-        nbytes = ((h * w + 31) // 32) * 4
-        bits = np.unpackbits(masks[mask_offset[i]:mask_offset[i] + nbytes], bitorder='little')[:h * w].reshape(h, w)
-        fr, fc = int(r['fg_r0']) - r0, int(r['fg_c0']) - c0
-        out.append((np.array([int(r['fg_r0']), int(r['fg_c0'])]), bits[fr:fr + int(r['fg_h']), fc:fc + int(r['fg_w'])].astype(bool)))
-    return out
+    """Foreground fragments from bit-packed region-bbox masks (engine.fragments_from_masks: host code of the C ABI)."""
+    from . import engine
+    return engine.fragments_from_masks(records, mask_info, mask_offset, masks)
 
 
 class Sharder:
     """Splits every batch of candidates over the ranks of a process group and all-gathers the results, so that every
     rank can continue the (cheap, deterministic) host-side generation logic in lock step.
 
-    Per batch: each rank solves its cost-balanced share on its own GPU (no data-path collective), then ONE
-    all-gather of a padded byte block per rank: records (128 B / candidate), mask boxes and the bit-packed masks.
-    """
+    Per batch: each rank solves its cost-balanced share on its own GPU (no data-path collective), then ONE all-gather of a
+    padded byte block per rank -- records (128 B / candidate) and the bit-packed masks, packed on the device and gathered
+    device to device (RCCL); one download of the gathered block follows.  Nothing else is exchanged: shards, mask boxes and
+    every rank's payload size follow from the image statistics that all ranks hold (the plan is host arithmetic)."""
 
     def __init__(self, group=None, device=None, solve_local=_gpu_solve_local):
         self.group = group
@@ -115,41 +113,59 @@ class Sharder:
         self.solve_local = solve_local
 
     def solve(self, image, footprints, cfg):
-        from . import _capi
+        from . import _capi, engine
         n = len(footprints)
-        stats = getattr(image, 'atom_stats', None)
-        if stats is not None:
-            area = np.asarray(stats).reshape(-1, 6)[:, 0]
-            costs = [sum(int(area[a]) for a in fp if 0 < a < len(area)) for fp in footprints]
-        else:
-            costs = [len(fp) for fp in footprints]
+        footprints = [sorted(int(a) for a in fp) for fp in footprints]
+        area = np.asarray(image.atom_stats).reshape(-1, 6)[:, 0]
+        costs = [sum(int(area[a]) for a in fp if 0 < a < len(area)) for fp in footprints]
         shards = shard_indices(costs, self.world)
+        # mask boxes of all candidates and with them every rank's payload size: host-only planning, identical on all ranks
+        mask_info = engine.plan_mask_boxes(image, footprints, cfg)
+        words = (mask_info[:, 2].astype(np.int64) * mask_info[:, 3] + 31) // 32
+        nrec = [128 * len(sh) for sh in shards]
+        nmask = [max(4, int(4 * words[sh].sum())) for sh in shards]       # (an empty plan still has a 4-byte mask buffer)
+        pad = max(a + b for a, b in zip(nrec, nmask))
         mine = shards[self.rank]
-        rec_b, info, off, masks = self.solve_local(image, [footprints[i] for i in mine], cfg)
-        payload = np.concatenate([np.asarray(rec_b, np.uint8).reshape(-1), np.ascontiguousarray(info, np.int32).view(np.uint8).reshape(-1),
-                                  np.ascontiguousarray(off, np.int64).view(np.uint8).reshape(-1), np.asarray(masks, np.uint8).reshape(-1)])
-        dev = self.device if self.device is not None else (image.device if hasattr(image, 'device') else 'cpu')
-        size = torch.tensor([payload.size], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros_like(size) for _ in range(self.world)]
-        dist.all_gather(sizes, size, group=self.group)
-        sizes = [int(s.item()) for s in sizes]
-        pad = max(sizes)
+        res = self.solve_local(image, [footprints[i] for i in mine], cfg, mask_info[mine])
+        rec_t, mask_t = res[0], res[1]
+        dev = rec_t.device if self.device is None else torch.device(self.device)
         send = torch.zeros(pad, dtype=torch.uint8, device=dev)
-        send[:payload.size] = torch.from_numpy(payload).to(dev)
-        recv = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(self.world)]
-        dist.all_gather(recv, send, group=self.group)                 # the one data collective of the batch
+        send[:nrec[self.rank]].copy_(rec_t.reshape(-1)[:nrec[self.rank]])
+        send[nrec[self.rank]:nrec[self.rank] + nmask[self.rank]].copy_(mask_t.reshape(-1)[:nmask[self.rank]])
+        recv = torch.empty(self.world * pad, dtype=torch.uint8, device=dev)
+        if dist.get_backend(self.group) == 'gloo' and send.is_cuda:          # rehearsal on one GPU: gloo moves host memory
+            hs, hr = send.cpu(), torch.empty(self.world * pad, dtype=torch.uint8)
+            dist.all_gather(list(hr.chunk(self.world)), hs, group=self.group)
+            host = hr.numpy()
+        else:
+            dist.all_gather(list(recv.chunk(self.world)), send, group=self.group)   # the one collective of the batch
+            host = recv.cpu().numpy()
         records = np.zeros(n, _capi.RECORD_DTYPE)
         fragments = [None] * n
         for r in range(self.world):
             idx = shards[r]
-            k = len(idx)
-            buf = recv[r].cpu().numpy()[:sizes[r]]
-            rec = buf[:k * 128].view(_capi.RECORD_DTYPE)
-            inf = buf[k * 128:k * 144].view(np.int32).reshape(k, 4)
-            ofs = buf[k * 144:k * 152].view(np.int64)
-            msk = buf[k * 152:]
-            frs = fragments_from_masks(rec, inf, ofs, msk)
+            if len(idx) == 0:
+                continue
+            buf = host[r * pad:(r + 1) * pad]
+            rec = buf[:nrec[r]].view(_capi.RECORD_DTYPE)
+            ofs = np.concatenate([[0], np.cumsum(4 * words[idx])[:-1]]).astype(np.int64)
+            frs = engine.fragments_from_masks(rec, mask_info[idx], ofs, buf[nrec[r]:nrec[r] + nmask[r]])
+            records[idx] = rec
             for j, i in enumerate(idx):
-                records[i] = rec[j]
                 fragments[i] = frs[j]
         return records, fragments
+
+
+def deal_images(n_images, world):
+    """Image sets (BASELINE.json configs[3]): whole images are dealt to the ranks round-robin; every rank runs the stage on its
+    images (GlobalEnergyMinimization.process_many) and the per-image results are gathered once at the end."""
+    return [list(range(r, n_images, world)) for r in range(world)]
+
+
+def gather_objects(local, group=None, dst=0):
+    """The one gather at the end of an image-set run: every rank's list of picklable per-image results to rank ``dst``
+    (None elsewhere), in rank order."""
+    world = dist.get_world_size(group)
+    out = [None] * world if dist.get_rank(group) == dst else None
+    dist.gather_object(local, out, dst=dst, group=group)
+    return out

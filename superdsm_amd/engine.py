@@ -70,27 +70,93 @@ class DeviceImage:
         self.atom_stats = np.ascontiguousarray(stats.cpu().numpy())       # host copy used by the planner (synchronises)
 
 
-class Batch:
-    """One ``compute_objects`` call: plan, workspace, launch, results."""
+def fragments_from_masks(records, mask_info, mask_offset, masks, select=None):
+    """Foreground fragments (bool arrays, views into one buffer) and offsets from downloaded records and bit-packed
+    region-bbox masks (objects.py:148-174); ``select`` (bool per candidate) skips the others (``(None, None)``)."""
+    L = _capi.lib()
+    n = len(records)
+    records = np.ascontiguousarray(records)
+    mask_info = np.ascontiguousarray(mask_info[:n], np.int32)
+    mask_offset = np.ascontiguousarray(mask_offset[:n], np.int64)
+    masks = np.ascontiguousarray(masks, np.uint8)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    off = np.zeros(n + 1, np.int64)
+    total = L.sdsm_unpack_fragments(ptr(records), ptr(mask_info), ptr(mask_offset), ptr(masks), n, None, ptr(off))
+    if total < 0:
+        raise _capi.SdsmError('sdsm_unpack_fragments: ' + L.sdsm_last_error().decode())
+    buf = np.empty(max(total, 1), np.uint8)
+    L.sdsm_unpack_fragments(ptr(records), ptr(mask_info), ptr(mask_offset), ptr(masks), n, ptr(buf), ptr(off))
+    off[n] = total
+    fb = buf.view(bool)
+    empty = (records['fg_h'] <= 0) | np.isin(records['status'], (_capi.CAND_TRIVIAL, _capi.CAND_ERROR, _capi.CAND_GIVEN_UP))
+    fh = np.where(empty, 1, records['fg_h']).tolist()
+    fw = np.where(empty, 1, records['fg_w']).tolist()
+    origin = np.stack([np.where(empty, 0, records['fg_r0']), np.where(empty, 0, records['fg_c0'])], axis=1).astype(int)
+    offs = off.tolist()
+    out = []
+    for i in range(n):
+        if select is not None and not select[i]:
+            out.append((None, None))
+        else:
+            out.append((origin[i], fb[offs[i]:offs[i + 1]].reshape(fh[i], fw[i])))
+    return out
 
-    def __init__(self, image, footprints, dsm_cfg, want_xi=False, latency_mode=False):
-        """latency_mode: give the largest regions a 512-thread workgroup each (shortest wall clock of ONE batch);
-        default: most candidate solves per second with several batches in flight (sdsm_plan_set_latency_mode)."""
+
+def plan_mask_boxes(image, footprints, dsm_cfg):
+    """Region bounding boxes (r0, c0, h, w) of candidates, [n, 4] int32: host-only planning from the per-atom statistics
+    (sdsm_plan_create + sdsm_plan_describe; no device access).  ``image`` needs H, W, n_atoms, atom_stats, background_margin."""
+    L = _capi.lib()
+    n = len(footprints)
+    offs = np.zeros(n + 1, np.int32)
+    np.cumsum(np.fromiter((len(fp) for fp in footprints), np.int64, n), out=offs[1:])
+    labels = np.fromiter((int(a) for fp in footprints for a in fp), np.int32, int(offs[-1]))
+    cfg = _capi.make_config(dict(dsm_cfg, background_margin=image.background_margin))
+    stats = np.ascontiguousarray(image.atom_stats, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    plan = L.sdsm_plan_create(int(image.H), int(image.W), int(image.n_atoms), p(stats), C.byref(cfg), n, p(offs), p(labels))
+    if not plan:
+        raise _capi.SdsmError('sdsm_plan_create failed: ' + L.sdsm_last_error().decode())
+    info = np.zeros((max(n, 1), 4), np.int32)
+    _capi.check(L.sdsm_plan_describe(plan, p(info), None, None), 'sdsm_plan_describe')
+    L.sdsm_plan_destroy(plan)
+    return info[:n]
+
+
+class Batch:
+    """One ``compute_objects`` call: plan, workspace, launch, results.  ``image`` may be a list of :class:`DeviceImage` (a plan
+    over several images, sdsm_plan_create_multi): ``image_of[i]`` then names the image of candidate ``i``."""
+
+    def __init__(self, image, footprints, dsm_cfg, want_xi=False, latency_mode=False, image_of=None, mode=None):
+        """mode: 0 throughput (default), 1 latency (``latency_mode=True``: the largest regions get a group of 512-thread
+        workgroups, shortest wall clock of ONE batch), 2 no workgroup groups (sdsm_plan_set_latency_mode)."""
         L = _capi.lib()
-        self.image = image
+        self.images = list(image) if isinstance(image, (list, tuple)) else [image]
+        self.image = self.images[0]
+        assert 1 <= len(self.images) <= 16, 'a plan covers 1 .. 16 images'
         self.n = len(footprints)
-        self.footprints = [sorted(int(a) for a in fp) for fp in footprints]
+        lens = np.fromiter((len(fp) for fp in footprints), np.int64, self.n)
         offs = np.zeros(self.n + 1, np.int32)
-        offs[1:] = np.cumsum([len(fp) for fp in self.footprints])
-        labels = np.ascontiguousarray(np.concatenate(self.footprints) if self.n else np.zeros(0), dtype=np.int32)
-        self.cfg = _capi.make_config(dict(dsm_cfg, background_margin=image.background_margin))
-        self.plan = L.sdsm_plan_create(image.H, image.W, image.n_atoms, image.atom_stats.ctypes.data_as(C.c_void_p), C.byref(self.cfg),
-                                       self.n, offs.ctypes.data_as(C.c_void_p), labels.ctypes.data_as(C.c_void_p))
+        np.cumsum(lens, out=offs[1:])
+        labels = np.fromiter((int(a) for fp in footprints for a in fp), np.int32, int(offs[-1]))
+        self.image_of = None if image_of is None else np.ascontiguousarray(image_of, np.int32)
+        assert len(self.images) == 1 or (self.image_of is not None and len(self.image_of) == self.n)
+        margins = {im.background_margin for im in self.images}
+        assert len(margins) == 1, 'all images of a plan share the hyper-parameters'
+        self.cfg = _capi.make_config(dict(dsm_cfg, background_margin=self.image.background_margin))
+        ni = len(self.images)
+        Hs = np.array([im.H for im in self.images], np.int32)
+        Ws = np.array([im.W for im in self.images], np.int32)
+        nas = np.array([im.n_atoms for im in self.images], np.int32)
+        stats = (C.c_void_p * ni)(*[im.atom_stats.ctypes.data for im in self.images])
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.plan = L.sdsm_plan_create_multi(ni, p(Hs), p(Ws), p(nas), stats, C.byref(self.cfg), self.n, p(offs), p(labels),
+                                             p(self.image_of) if self.image_of is not None else None)
         if not self.plan:
             raise _capi.SdsmError('sdsm_plan_create failed: ' + L.sdsm_last_error().decode())
-        if latency_mode:
-            _capi.check(L.sdsm_plan_set_latency_mode(self.plan, 1), 'sdsm_plan_set_latency_mode')
-        dev = image.device
+        self.mode = (1 if latency_mode else 0) if mode is None else int(mode)
+        if self.mode:
+            _capi.check(L.sdsm_plan_set_latency_mode(self.plan, self.mode), 'sdsm_plan_set_latency_mode')
+        dev = self.image.device
         self.ws_bytes = L.sdsm_plan_workspace_bytes(self.plan)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.records_dev = torch.zeros(max(self.n, 1) * _capi.RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
@@ -100,9 +166,10 @@ class Batch:
         self.mask_info = np.zeros((max(self.n, 1), 4), np.int32)
         self.mask_offset = np.zeros(max(self.n, 1), np.int64)
         self.n_pixels = np.zeros(max(self.n, 1), np.int32)
-        _capi.check(L.sdsm_plan_describe(self.plan, self.mask_info.ctypes.data_as(C.c_void_p), self.mask_offset.ctypes.data_as(C.c_void_p),
-                                         self.n_pixels.ctypes.data_as(C.c_void_p)), 'sdsm_plan_describe')
+        _capi.check(L.sdsm_plan_describe(self.plan, p(self.mask_info), p(self.mask_offset), p(self.n_pixels)), 'sdsm_plan_describe')
         self.total_pixels = L.sdsm_plan_total_pixels(self.plan)
+        self._host = None
+        self._ptrs = tuple((C.c_void_p * ni)(*[getattr(im, k).data_ptr() for im in self.images]) for k in ('y', 'atoms', 'valid'))
         with torch.cuda.device(dev):
             _capi.check(L.sdsm_batch_upload(self.plan, _ptr(self.ws), self.ws_bytes, _stream()), 'sdsm_batch_upload')
 
@@ -115,10 +182,20 @@ class Batch:
     def launch(self):
         """Queues the setup and solve kernels on the current stream (asynchronous)."""
         L = _capi.lib()
-        im = self.image
-        with torch.cuda.device(im.device):
-            _capi.check(L.sdsm_batch_launch(self.plan, _ptr(im.y), _ptr(im.atoms), _ptr(im.valid), _ptr(self.ws), self.ws_bytes,
-                                            _ptr(self.records_dev), _ptr(self.masks_dev), _ptr(self.xi_dev), _stream()), 'sdsm_batch_launch')
+        with torch.cuda.device(self.image.device):
+            _capi.check(L.sdsm_batch_launch_multi(self.plan, self._ptrs[0], self._ptrs[1], self._ptrs[2], _ptr(self.ws), self.ws_bytes,
+                                                  _ptr(self.records_dev), _ptr(self.masks_dev), _ptr(self.xi_dev), _stream()), 'sdsm_batch_launch_multi')
+
+    def download(self):
+        """Records and bit-packed masks to pinned host buffers: two asynchronous copies on the current stream, one
+        synchronisation.  Returns (records structured array, masks uint8 array) -- views, valid until the next download."""
+        if self._host is None:
+            self._host = (torch.empty(self.records_dev.numel(), dtype=torch.uint8).pin_memory(), torch.empty(self.masks_dev.numel(), dtype=torch.uint8).pin_memory())
+        with torch.cuda.device(self.image.device):
+            self._host[0].copy_(self.records_dev, non_blocking=True)
+            self._host[1].copy_(self.masks_dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        return self._host[0].numpy().view(_capi.RECORD_DTYPE)[:self.n], self._host[1].numpy()
 
     def records(self):
         return self.records_dev.cpu().numpy().view(_capi.RECORD_DTYPE)[:self.n].copy()
@@ -199,25 +276,11 @@ class Batch:
             po += N
         return out
 
-    def fragments(self, records, select=None):
+    def fragments(self, records, select=None, masks=None):
         """Foreground fragments (bool arrays) and offsets, cropped from the bit-packed region-bbox masks."""
-        masks = self.masks_dev.cpu().numpy()
-        out = []
-        for i in range(self.n):
-            if select is not None and not select[i]:
-                out.append((None, None))
-                continue
-            r = records[i]
-            if r['fg_h'] <= 0 or r['status'] in (_capi.CAND_TRIVIAL, _capi.CAND_ERROR):
-                out.append((np.zeros(2, int), np.zeros((1, 1), bool)))        # objects.py:172-174, 185-186
-                continue
-            r0, c0, h, w = (int(v) for v in self.mask_info[i])
-            nbytes = ((h * w + 31) // 32) * 4
-            bits = np.unpackbits(masks[self.mask_offset[i]:self.mask_offset[i] + nbytes], bitorder='little')[:h * w].reshape(h, w)
-            fr, fc = int(r['fg_r0']) - r0, int(r['fg_c0']) - c0
-            frag = bits[fr:fr + int(r['fg_h']), fc:fc + int(r['fg_w'])].astype(bool)
-            out.append((np.array([int(r['fg_r0']), int(r['fg_c0'])]), frag))
-        return out
+        if masks is None:
+            masks = self.masks_dev.cpu().numpy()
+        return fragments_from_masks(records, self.mask_info, self.mask_offset, masks, select)
 
 
 def algorithmic_bytes(records, mask_info):

@@ -8,13 +8,15 @@ generation / pruning logic is host-side bookkeeping and is restated here; every 
 batch.
 """
 import os
+import threading
+import time
 
 import numpy as np
 
 from .image import Image
 from .maxsetpack import solve_maxsetpack
 from .minsetcover import DEFAULT_GAMMA, DEFAULT_MAX_ITER, MinSetCover
-from .objects import Object, compute_objects
+from .objects import Object, compute_objects, compute_objects_multi
 from .output import Text, get_output
 from .pipeline import Stage
 
@@ -124,7 +126,7 @@ def _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=D
 
 
 def _process_generation(cover, objects, previous_generation, y, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
-                        log_root_dir, pruning, ignored_cluster_labels, out, shard=None):
+                        log_root_dir, pruning, ignored_cluster_labels, out, shard=None, solver=None):
     """One generation: enumerate, prune by the energy bound, solve the survivors as ONE batch, keep those below
     their threshold (globalenergymin.py:326-368)."""
     new_objects, thresholds = [], []
@@ -154,7 +156,7 @@ def _process_generation(cover, objects, previous_generation, y, atoms_map, adjac
             raise ValueError(f'Unknown pruning mode "{pruning}"')
         new_objects.append(candidate)
 
-    compute_objects(new_objects, y, atoms_map, dsm_cfg, log_root_dir, out=out, shard=shard)
+    (solver or compute_objects)(new_objects, y, atoms_map, dsm_cfg, log_root_dir, out=out, shard=shard)
 
     next_generation = []
     for idx, (obj, threshold) in enumerate(zip(new_objects, thresholds)):
@@ -169,9 +171,11 @@ def _process_generation(cover, objects, previous_generation, y, atoms_map, adjac
 
 
 def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, dsm_cfg, beta=np.nan, max_iter=DEFAULT_MAX_ITER,
-                         gamma=DEFAULT_GAMMA, max_seed_distance=np.inf, max_work_amount=DEFAULT_MAX_WORK_AMOUNT, out=None, shard=None):
-    """Returns ``(generations, costs, cover, objects, performance)`` (globalenergymin.py:183-271)."""
+                         gamma=DEFAULT_GAMMA, max_seed_distance=np.inf, max_work_amount=DEFAULT_MAX_WORK_AMOUNT, out=None, shard=None, solver=None):
+    """Returns ``(generations, costs, cover, objects, performance)`` (globalenergymin.py:183-271).  ``solver``: stands in for
+    :func:`compute_objects` (same signature) -- the lock-step driver of :meth:`GlobalEnergyMinimization.process_many`."""
     out = get_output(out)
+    solve = solver or compute_objects
 
     atoms = []
     for label in adjacencies.atom_labels:
@@ -179,7 +183,7 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         obj.footprint = {label}
         atoms.append(obj)
     out.write('\nIteration 1:')
-    compute_objects(atoms, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 1), out=out, shard=shard)
+    solve(atoms, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 1), out=out, shard=shard)
     atom_by_label = {next(iter(a.footprint)): a for a in atoms}
 
     universes = []
@@ -187,8 +191,8 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         obj = Object()
         obj.footprint = set(adjacencies.get_atoms_in_cluster(cluster))
         universes.append(obj)
-    compute_objects(universes, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 0),
-                    ('Computing universe costs', 'Universe costs computed'), out=out, shard=shard)
+    solve(universes, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 0),
+          ('Computing universe costs', 'Universe costs computed'), out=out, shard=shard)
 
     solved_directly, trivial = set(), set()        # Criterion 2 / universes of one or two atoms
     for cluster, universe in zip(adjacencies.cluster_labels, universes):
@@ -224,7 +228,7 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
             out.write(f'Iteration {number}: {Text.style(text, Text.BOLD)}')
             new_generation, new_objects = _process_generation(
                 cover, objects, generations[-1], y_img, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
-                _generation_log_dir(log_root_dir, number), pruning, solved_directly, out, shard=shard)
+                _generation_log_dir(log_root_dir, number), pruning, solved_directly, out, shard=shard, solver=solver)
             objects += new_objects
             performance.iterative_computed_object_count += len(new_objects)
             if not new_generation:
@@ -243,6 +247,48 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
     return generations, costs, cover, objects, performance
 
 
+
+class _LockStep:
+    """Rendezvous of the per-image threads of :meth:`GlobalEnergyMinimization.process_many`: ``submit`` has the signature of
+    :func:`compute_objects`; when every thread that is still running has submitted a batch, all of them are solved together."""
+
+    def __init__(self, n, out):
+        self.active, self.out = n, out
+        self.jobs, self.round, self.error = [], 0, None
+        self.cv = threading.Condition()
+        self.batches = 0                      # multi-image batches solved (diagnostics / tests)
+
+    def submit(self, objects, y, atoms, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None):
+        assert shard is None, 'process_many and sharded batches are separate ways to fill the GPUs'
+        with self.cv:
+            my_round = self.round
+            self.jobs.append((list(objects), y, atoms, dsm_cfg, log_root_dir))
+            if len(self.jobs) >= self.active:
+                self._flush()
+            while self.round == my_round and self.error is None:
+                self.cv.wait()
+            if self.error is not None:
+                raise self.error
+
+    def leave(self):
+        with self.cv:
+            self.active -= 1
+            if self.jobs and len(self.jobs) >= self.active:
+                self._flush()
+
+    def _flush(self):
+        jobs, self.jobs = self.jobs, []
+        try:
+            cfg = jobs[0][3]
+            assert all(j[3] == cfg for j in jobs), 'the images of one lock-step run share the dsm/* hyper-parameters'
+            compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out)
+            self.batches += 1
+        except BaseException as e:               # noqa: BLE001 -- handed to every waiting thread
+            self.error = e
+        self.round += 1
+        self.cv.notify_all()
+
+
 class GlobalEnergyMinimization(Stage):
     """Stage ``global-energy-minimization``.  ``shard`` (optional): a :class:`superdsm_amd.dist.Sharder` that splits
     every batch of candidates over the ranks of a process group."""
@@ -255,8 +301,8 @@ class GlobalEnergyMinimization(Stage):
                          outputs=['y_img', 'cover', 'objects', 'performance'])
         self.shard = shard
 
-    def process(self, input_data, cfg, out, log_root_dir):
-        y_img = Image.create_from_array(input_data['y'], normalize=False, mask=input_data['y_mask'])
+    @staticmethod
+    def _hyperparameters(cfg):
         pruning = cfg.get('pruning', 'exact')
         beta = cfg.get('beta', 0)
         max_iter = cfg.get('max_iter', DEFAULT_MAX_ITER)
@@ -265,10 +311,58 @@ class GlobalEnergyMinimization(Stage):
         max_work_amount = cfg.get('max_work_amount', DEFAULT_MAX_WORK_AMOUNT)
         assert 0 < gamma < 1
         assert pruning in ('exact', 'isbi24')
+        return pruning, beta, max_iter, gamma, max_seed_distance, max_work_amount
+
+    def process(self, input_data, cfg, out, log_root_dir, solver=None):
+        y_img = Image.create_from_array(input_data['y'], normalize=False, mask=input_data['y_mask'])
+        pruning, beta, max_iter, gamma, max_seed_distance, max_work_amount = self._hyperparameters(cfg)
         _, _, cover, objects, performance = _compute_generations(
             input_data['adjacencies'], y_img, input_data['atoms'], log_root_dir, pruning, dict(input_data['dsm_cfg']),
-            beta, max_iter, gamma, max_seed_distance, max_work_amount, out, shard=self.shard)
+            beta, max_iter, gamma, max_seed_distance, max_work_amount, out, shard=self.shard, solver=solver)
         return {'y_img': y_img, 'cover': cover, 'objects': objects, 'performance': performance}
+
+    def process_many(self, datas, cfg, out=None, log_root_dirs=None):
+        """The stage for SEVERAL images in lock step (an image set as examples/NIH3T3, BASELINE.json configs[3]): generation k
+        of every image is solved as ONE multi-image batch (objects.compute_objects_multi).  The generations of one image are
+        sequential (globalenergymin.py:228-263) and hold only tens of candidates each -- far too few to fill a GPU; those of
+        different images are independent.  Every image runs the unchanged host logic in a thread of its own; the threads
+        meet whenever they need candidates solved.
+
+        Used like ``Stage.__call__``, image by image: ``datas`` is a list of pipeline data dicts (the stage's inputs are read
+        from, its outputs written to each), ``cfg`` one :class:`Config` for all or a list; returns the wall time.  The results
+        equal those of calling the stage on every image separately."""
+        datas = list(datas)
+        cfgs = list(cfg) if isinstance(cfg, (list, tuple)) else [cfg] * len(datas)
+        cfgs = [c.get(self.cfgns, {}) for c in cfgs]
+        logs = list(log_root_dirs) if log_root_dirs is not None else [None] * len(datas)
+        out = get_output(out)
+        lock = _LockStep(len(datas), out)
+        self.last_lockstep = lock
+        produced, errors = [None] * len(datas), [None] * len(datas)
+        t0 = time.time()
+
+        def work(i):
+            try:
+                stage_input = {inner: datas[i][outer] for outer, inner in self.inputs.items()}
+                produced[i] = self.process(stage_input, cfgs[i], out.derive(muted=True), logs[i], solver=lock.submit)
+            except BaseException as e:            # noqa: BLE001 -- re-raised in the calling thread
+                errors[i] = e
+            finally:
+                lock.leave()
+
+        threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(datas))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in errors:
+            if e is not None:
+                raise e
+        for data, prod in zip(datas, produced):
+            assert set(prod.keys()) == set(self.outputs), 'stage "%s" generated unexpected output' % self.name
+            for inner, outer in self.outputs.items():
+                data[outer] = prod[inner]
+        return time.time() - t0
 
     def configure_ex(self, scale, radius, diameter):
         return {

@@ -6,7 +6,9 @@ atom labels) and, after :func:`compute_objects`, ``energy``, ``on_boundary``, ``
 contract, but instead of one Ray task per candidate (objects.py:275-281) the whole list becomes ONE batch of the HIP
 engine (region crops, G~ rows, elliptical + DSM solves, masks).  There is no CPU path.
 """
+import os
 import time
+import zlib
 
 import numpy as np
 
@@ -88,22 +90,123 @@ DEFAULT_COMPUTING_STATUS_LINE = ('Computing objects', 'Computed objects')
 _CPU_ONLY_KEYS = ('smooth_mat_max_allocations', 'cachesize', 'cachetest', 'smooth_mat_dtype', 'cp_timeout')
 
 
-def _device_image(y, atoms, background_margin):
-    """The per-image device state is cached on the ``Image`` object: y, atoms and the candidate-independent
-    validity mask are uploaded / computed once, not once per candidate (objects.py:126-127 does the latter)."""
+def _fingerprint(a):
+    """Cheap content fingerprint of an array: identity, shape and a CRC of a strided sample (an in-place edit or a new array
+    at a recycled address changes it with overwhelming probability; a full CRC would cost as much as a small batch)."""
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 4096)
+    return (id(a), a.shape, str(a.dtype), zlib.crc32(np.ascontiguousarray(flat[::step]).tobytes()))
+
+
+def device_image(y, atoms, background_margin, refresh=False):
+    """The per-image device state, cached on the ``Image`` object: y, atoms and the candidate-independent validity mask are
+    uploaded / computed once, not once per candidate (objects.py:126-127 does the latter).  The cache is keyed by a content
+    fingerprint of ``atoms`` / ``y.model`` / ``y.mask`` and the margin; ``refresh=True`` rebuilds it unconditionally
+    (GlobalEnergyMinimization.process does that once per call)."""
     from . import engine
     cache = getattr(y, '_sdsm_device', None)
-    key = (id(atoms), float(background_margin))
-    if cache is None or cache[0] != key:
+    key = (_fingerprint(atoms), _fingerprint(y.model), None if y.mask is None else _fingerprint(y.mask), float(background_margin))
+    if refresh or cache is None or cache[0] != key:
         mask = None if y.mask is None or y.mask.all() else y.mask
         cache = (key, engine.DeviceImage(y.model, mask, atoms, background_margin))
         y._sdsm_device = cache
     return cache[1]
 
 
+_device_image = device_image
+
+
 def compute_norm_energy(obj):
     """``postprocess._compute_norm_energy`` (postprocess.py:289-291) without recomputing the region: compute_objects keeps its size."""
     return obj.energy / obj.cvxprog_region_size
+
+
+_STATUS_NAMES = {_capi.CAND_OPTIMAL: 'optimal', _capi.CAND_FALLBACK: 'fallback', _capi.CAND_TRIVIAL: 'trivial (single positive pixel)',
+                 _capi.CAND_ERROR: 'error', _capi.CAND_UNSUPPORTED: 'unsupported', _capi.CAND_GIVEN_UP: 'given up (scheduling)'}
+
+
+def _write_logs(log_root_dir, records):
+    """One ``<cidx>.txt`` per candidate, as the reference's workers do (objects.py:220-237 redirect the solver's output there);
+    here the solver's counters and outcome."""
+    if log_root_dir is None:
+        return
+    os.makedirs(log_root_dir, exist_ok=True)
+    for cidx, r in enumerate(records):
+        with open(os.path.join(log_root_dir, f'{cidx}.txt'), 'w') as f:
+            f.write(f'status: {_STATUS_NAMES.get(int(r["status"]), int(r["status"]))}\n'
+                    f'region pixels N: {int(r["n_pixels"])}  deformation parameters M: {int(r["n_deform"])}\n'
+                    f'elliptical model: {int(r["iters_ell"])} Newton iterations, psi = {float(r["energy_ell"])!r}'
+                    f'{" (retry from the moment initialisation)" if int(r["flags"]) & 1 else ""}\n'
+                    f'deformable model: {int(r["iters_dsm"])} Newton iterations, psi = {float(r["energy"])!r}\n'
+                    f'passes over the pixels: {int(r["evals_full"])} full, {int(r["evals_value"])} value / line search\n'
+                    f'theta: {np.asarray(r["theta"]).tolist()}\n')
+
+
+def _solve(images, footprints, image_of, cfg, shard):
+    """One batch over one or several images -> (records, fragments).  Candidates whose workgroup group was given up (a
+    scheduling event on an oversubscribed GPU, not a solver failure) are solved again without groups."""
+    from . import engine
+    import torch
+    if shard is not None:
+        assert len(images) == 1, 'sharded batches cover one image'
+        return shard.solve(images[0], footprints, cfg)
+    batch = engine.Batch(images if len(images) > 1 else images[0], footprints, cfg, image_of=image_of,
+                         mode=1 if len(images) == 1 else 0)        # one image at a time: shortest wall clock; several: fill the GPU
+    batch.launch()
+    records, masks = batch.download()
+    records = records.copy()
+    fragments = batch.fragments(records, masks=masks)
+    again = np.flatnonzero(records['status'] == _capi.CAND_GIVEN_UP)
+    if again.size:
+        sub = engine.Batch(images if len(images) > 1 else images[0], [footprints[i] for i in again], cfg,
+                           image_of=None if image_of is None else np.asarray(image_of)[again], mode=2)
+        sub.launch()
+        rec2, masks2 = sub.download()
+        frag2 = sub.fragments(rec2, masks=masks2)
+        for j, i in enumerate(again):
+            records[i] = rec2[j]
+            fragments[i] = (frag2[j][0], frag2[j][1].copy())
+    return records, fragments
+
+
+def _assign(objects, records, fragments, dt, cidx0=0):
+    fallbacks = 0
+    status = records['status'].tolist()
+    energy = records['energy'].tolist()
+    onb = records['on_boundary'].tolist()
+    npx = records['n_pixels'].tolist()
+    per = dt / max(1, len(objects))
+    for k, obj in enumerate(objects):
+        st = status[k]
+        if st == _capi.CAND_ERROR:
+            raise CvxprogError('convex programming failed for the elliptical model', cidx=cidx0 + k)
+        if st == _capi.CAND_UNSUPPORTED:
+            raise _capi.SdsmError(f'candidate {cidx0 + k} exceeds an implementation limit of the GPU solver '
+                                  f'(N={npx[k]}, M={int(records["n_deform"][k])}); see DESIGN.md "Limits"')
+        if st == _capi.CAND_GIVEN_UP:
+            raise _capi.SdsmError(f'candidate {cidx0 + k}: the GPU could not schedule its workgroup group, also on the second attempt (not a solver failure)')
+        obj.fg_offset, obj.fg_fragment = fragments[k]
+        obj.energy = energy[k]
+        obj.on_boundary = bool(onb[k])
+        obj.is_optimal = st == _capi.CAND_OPTIMAL
+        # size of the convex-programming region: what postprocess._compute_norm_energy divides by (postprocess.py:289-291; the
+        # reference recomputes the region with a full-image distance transform per object)
+        obj.cvxprog_region_size = npx[k]
+        # the batch is solved concurrently: the wall time is attributed evenly (the reference records the per-task time)
+        obj.processing_time = 0 if st == _capi.CAND_TRIVIAL else per
+        fallbacks += st == _capi.CAND_FALLBACK
+    return fallbacks
+
+
+def _clean_cfg(dsm_cfg):
+    cfg = {k: v for k, v in dsm_cfg.items() if k not in _CPU_ONLY_KEYS}
+    if callable(cfg.get('init')):
+        raise NotImplementedError('dsm/init as a callable is not supported by the GPU solver')
+    for key in ('sparsity_tol', 'hessian_sparsity_tol'):
+        if cfg.pop(key, 0) != 0:
+            raise NotImplementedError(f'dsm/{key} != 0 changes the reference\'s results (dsm.py:346,362,377) and is not implemented by the GPU solver')
+    return cfg
 
 
 def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, shard=None):
@@ -114,49 +217,54 @@ def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAUL
     :param y: :class:`~superdsm_amd.image.Image` of offset intensities (``model``) with its ``mask``.
     :param atoms: int image of atom labels.
     :param dsm_cfg: the ``dsm/*`` hyper-parameters (dsmcfg.py:6-21).
-    :param log_root_dir: accepted for API compatibility; per-candidate log files are not written.
+    :param log_root_dir: directory that receives one ``<cidx>.txt`` per candidate (objects.py:220-237), or ``None``.
     :param shard: optional :class:`superdsm_amd.dist.Sharder`: solve only this rank's share, all-gather the results.
     """
-    from . import engine
-    import torch
     out = get_output(out)
     objects = list(objects)
-    cfg = {k: v for k, v in dsm_cfg.items() if k not in _CPU_ONLY_KEYS}
-    if callable(cfg.get('init')):
-        raise NotImplementedError('dsm/init as a callable is not supported by the GPU solver')
+    cfg = _clean_cfg(dsm_cfg)
     if len(objects) == 0:
         out.write(f'{status_line[1]}: 0 (0x fallback)')
         return
     margin = cfg.pop('background_margin', 20)
-    image = _device_image(y, atoms, margin)
+    image = device_image(y, atoms, margin)
     out.intermediate(f'{status_line[0]}... 0 / {len(objects)}')
     t0 = time.time()
-    footprints = [sorted(int(a) for a in obj.footprint) for obj in objects]
-    if shard is not None:
-        records, fragments = shard.solve(image, footprints, cfg)
-    else:
-        batch = engine.Batch(image, footprints, cfg, latency_mode=True)     # one image at a time: shortest wall clock
-        batch.launch()
-        torch.cuda.synchronize(image.device)
-        records = batch.records()
-        fragments = batch.fragments(records)
+    records, fragments = _solve([image], [obj.footprint for obj in objects], None, cfg, shard)
     dt = time.time() - t0
-    fallbacks = 0
-    for cidx, (obj, rec, (off, frag)) in enumerate(zip(objects, records, fragments)):
-        status = int(rec['status'])
-        if status == _capi.CAND_ERROR:
-            raise CvxprogError('convex programming failed for the elliptical model', cidx=cidx)
-        if status == _capi.CAND_UNSUPPORTED:
-            raise _capi.SdsmError(f'candidate {cidx} exceeds an implementation limit of the GPU solver '
-                                  f'(N={int(rec["n_pixels"])}, M={int(rec["n_deform"])}); see DESIGN.md "Limits"')
-        obj.fg_offset, obj.fg_fragment = off, frag
-        obj.energy = float(rec['energy'])
-        obj.on_boundary = bool(rec['on_boundary'])
-        obj.is_optimal = status == _capi.CAND_OPTIMAL
-        # size of the convex-programming region: what postprocess._compute_norm_energy divides by (postprocess.py:289-291; the
-        # reference recomputes the region with a full-image distance transform per object)
-        obj.cvxprog_region_size = int(rec['n_pixels'])
-        # the batch is solved concurrently: the wall time is attributed evenly (the reference records the per-task time)
-        obj.processing_time = 0 if status == _capi.CAND_TRIVIAL else dt / len(objects)
-        fallbacks += status == _capi.CAND_FALLBACK
+    _write_logs(log_root_dir, records)
+    fallbacks = _assign(objects, records, fragments, dt)
     out.write(f'{status_line[1]}: {len(objects)} ({fallbacks}x fallback)')
+
+
+def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None):
+    """:func:`compute_objects` for several images at once: ``jobs`` is a list of ``(objects, y, atoms)``, all solved as ONE
+    batch of the engine (sdsm_plan_create_multi) -- the batches of a single small image (tens of candidates per generation,
+    globalenergymin.py:357) cannot fill a GPU, the same generation of several images can.  Results are set in place, job by job;
+    ``cidx`` of an error counts within its job.  More than 16 images are processed in groups of 16."""
+    out = get_output(out)
+    cfg = _clean_cfg(dsm_cfg)
+    margin = cfg.pop('background_margin', 20)
+    jobs = [(list(objs), y, atoms) for objs, y, atoms in jobs]
+    todo = [j for j, (objs, _, _) in enumerate(jobs) if len(objs)]
+    total = fb = 0
+    for g0 in range(0, len(todo), 16):
+        group = todo[g0:g0 + 16]
+        images = [device_image(jobs[j][1], jobs[j][2], margin) for j in group]
+        fps, image_of = [], []
+        for k, j in enumerate(group):
+            fps.extend(obj.footprint for obj in jobs[j][0])
+            image_of.extend([k] * len(jobs[j][0]))
+        t0 = time.time()
+        records, fragments = _solve(images, fps, np.asarray(image_of, np.int32), cfg, None)
+        dt = time.time() - t0
+        pos = 0
+        for j in group:
+            objs = jobs[j][0]
+            rec, frs = records[pos:pos + len(objs)], fragments[pos:pos + len(objs)]
+            if log_root_dirs is not None and log_root_dirs[j] is not None:
+                _write_logs(log_root_dirs[j], rec)
+            fb += _assign(objs, rec, frs, dt * len(objs) / len(fps))
+            pos += len(objs)
+            total += len(objs)
+    out.write(f'{status_line[1]}: {total} ({fb}x fallback)')

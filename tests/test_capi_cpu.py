@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f'{name} is declared in include/sdsm.h but not exported by libsdsm_hip.so'
     assert sorted(_capi.SYMBOLS) == declared, 'ctypes binding table and header disagree'
-    assert lib.sdsm_version() == 100
+    assert lib.sdsm_version() == 200
 
 
 def test_record_and_config_layout():

@@ -1,5 +1,5 @@
-"""The N > 1 path on CPU: world_size 2, gloo.  The collective plumbing (sizes exchange, padded gather, unpack)
-and the cost-balanced sharding are device independent."""
+"""The N > 1 path on CPU: world_size 2, gloo.  The collective plumbing (padded gather / all-gather, unpack), the cost-balanced
+sharding, the image-set dealing and bench.py's own rank start-up are device independent."""
 import os
 import socket
 
@@ -67,52 +67,82 @@ def test_shard_indices_balanced_and_complete():
         assert tot.max() / tot.mean() < 1.05
 
 
-def _fake_solve_local(image, footprints, cfg):
-    """Deterministic stand-in for the GPU engine: energy = 10 * sum(labels), a 2x3 mask box with a label-dependent bit
-    pattern.  Exercises exactly the byte layout the GPU path produces."""
+class _FakeImage:
+    """What a rank needs to know about the (replicated) image to plan a batch: shape and per-atom statistics."""
+    H, W, n_atoms, background_margin = 64, 80, 12, 4.0
+
+    def __init__(self):
+        st = np.zeros((self.n_atoms + 1, 6), np.int32)
+        for l in range(1, self.n_atoms + 1):
+            r0, c0 = 3 + 4 * (l % 5), 2 + 5 * l
+            st[l] = (6 + l, r0, r0 + 2 + l % 3, c0, c0 + 3 + l % 2, 0)       # area, rmin, rmax, cmin, cmax
+        self.atom_stats = st.reshape(-1)
+
+
+_CFG = dict(scale=1000, epsilon=1.0, alpha=0.033, smooth_amount=4, smooth_subsample=8, gaussian_shape_multiplier=2)
+
+
+def _fake_solve_local(image, footprints, cfg, mask_info):
+    """Deterministic stand-in for the GPU engine on exactly the byte layout the GPU path produces: 128-byte records and
+    bit-packed masks over the PLANNED region boxes (a label-dependent bit pattern), as uint8 tensors."""
     from superdsm_amd import _capi
     n = len(footprints)
     rec = np.zeros(n, _capi.RECORD_DTYPE)
-    info = np.zeros((n, 4), np.int32)
-    off = np.zeros(n, np.int64)
-    masks = np.zeros(4 * n, np.uint8)
+    words = (mask_info[:, 2].astype(np.int64) * mask_info[:, 3] + 31) // 32
+    masks = np.zeros(max(1, int(words.sum())), np.uint32)
+    pos = 0
     for i, fp in enumerate(footprints):
-        rec['energy'][i] = 10.0 * sum(fp)
-        rec['status'][i] = 0
-        rec['n_pixels'][i] = 6
-        r0, c0 = 3 + fp[0], 5 + len(fp)
-        info[i] = (r0, c0, 2, 3)
-        off[i] = 4 * i
-        bits = (sum(fp) * 37 + 1) & 0x3f
-        masks[4 * i] = bits
-        grid = np.array([(bits >> b) & 1 for b in range(6)], bool).reshape(2, 3)
+        r0, c0, h, w = (int(v) for v in mask_info[i])
+        rng = np.random.default_rng(sum(fp) * 131 + len(fp))
+        grid = rng.random((h, w)) < 0.4
+        grid[h // 2, w // 2] = True
+        flat = np.flatnonzero(grid.reshape(-1))
+        np.bitwise_or.at(masks, pos + flat // 32, np.uint32(1) << (flat % 32).astype(np.uint32))
         rr, cc = np.nonzero(grid)
+        rec['energy'][i] = 10.0 * sum(fp)
+        rec['n_pixels'][i] = h * w
         rec['fg_r0'][i], rec['fg_c0'][i] = r0 + rr.min(), c0 + cc.min()
         rec['fg_h'][i], rec['fg_w'][i] = rr.max() - rr.min() + 1, cc.max() - cc.min() + 1
-    return rec.view(np.uint8).reshape(-1), info, off, masks
+        pos += int(words[i])
+    return torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()), torch.from_numpy(masks.view(np.uint8).copy())
 
 
 def _shard_worker(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    from superdsm_amd import _capi, engine
     fps = [[a] for a in range(1, 12)] + [[a, a + 1] for a in range(1, 8)] + [[2, 3, 4]]
+    img = _FakeImage()
     sh = sdist.Sharder(device='cpu', solve_local=_fake_solve_local)
-    recs, frags = sh.solve(object(), fps, {})
-    solo_rec, info, off, masks = _fake_solve_local(None, fps, {})
-    from superdsm_amd import _capi
-    solo = solo_rec.view(_capi.RECORD_DTYPE)
-    solo_frags = sdist.fragments_from_masks(solo, info, off, masks)
-    ok = np.array_equal(recs['energy'], solo['energy'])
+    calls = []
+    real_gather = dist.all_gather
+    dist.all_gather = lambda *a, **k: calls.append(1) or real_gather(*a, **k)
+    recs, frags = sh.solve(img, fps, _CFG)
+    dist.all_gather = real_gather
+    info = engine.plan_mask_boxes(img, fps, _CFG)
+    solo_rec, solo_masks = _fake_solve_local(img, fps, _CFG, info)
+    solo = solo_rec.numpy().view(_capi.RECORD_DTYPE)
+    words = (info[:, 2].astype(np.int64) * info[:, 3] + 31) // 32
+    off = np.concatenate([[0], np.cumsum(4 * words)[:-1]]).astype(np.int64)
+    solo_frags = sdist.fragments_from_masks(solo, info, off, solo_masks.numpy())
+    ok = np.array_equal(recs['energy'], solo['energy']) and len(calls) == 1          # ONE collective per batch, no size exchange
     for a, b in zip(frags, solo_frags):
         ok &= np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # image sets: whole images dealt to ranks, one gather of the per-image results at the end
+    mine = sdist.deal_images(5, world)[rank]
+    got = sdist.gather_objects([(i, f'result of image {i}') for i in mine], dst=0)
+    if rank == 0:
+        flat = sorted(x for part in got for x in part)
+        ok &= flat == [(i, f'result of image {i}') for i in range(5)]
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_sharded_batch_equals_single_rank_world2_gloo():
-    """Every rank ends up with the full, correctly ordered result of the batch (records and mask fragments)."""
+    """Every rank ends up with the full, correctly ordered result of the batch (records and mask fragments) after exactly one
+    collective; image sets are dealt by image and gathered once."""
     ctx = mp.get_context('spawn')
     q = ctx.SimpleQueue()
     port = _free_port()
@@ -124,3 +154,20 @@ def test_sharded_batch_equals_single_rank_world2_gloo():
         assert p.exitcode == 0
     got = dict(q.get() for _ in range(2))
     assert got == {0: True, 1: True}
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts two child ranks itself (rendezvous on 127.0.0.1, gloo on a box
+    without GPUs) and prints ONE JSON line with n_gpus == 2; --dry-run skips the GPU work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run'],
+                         env=env, capture_output=True, timeout=180)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['ms_per_step'] == 2.0      # MAX over the ranks' (1 + rank)
