@@ -422,9 +422,9 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
 {
     if (!p || !d_y || !d_atoms || !d_valid || !d_ws || !d_records || !d_masks) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: null argument");
     for (size_t i = 0; i < p->images.size(); i++) if (!d_y[i] || !d_atoms[i] || !d_valid[i]) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: null image pointer");
-    if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_launch: workspace too small");
     if (p->uploaded_gen != p->layout_gen || p->uploaded_ws != d_ws)
         return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_launch: the plan's tables in this workspace are missing or stale (sdsm_batch_upload must follow sdsm_plan_create and every sdsm_plan_set_latency_mode)");
+    if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_launch: workspace too small");
     if (p->n == 0) return SDSM_OK;
     hipStream_t s = (hipStream_t)stream;
     BatchParams P = make_params(p, d_ws);

@@ -701,7 +701,7 @@ def test_synthetic4096_matches_oracle(gpu):
     its = recs['iters_ell'] + recs['iters_dsm']
     sample = set(order[-12:].tolist()) | set(order[:6].tolist()) | set(order[len(order) // 2 - 3:len(order) // 2 + 3].tolist())
     sample |= set(np.argsort(recs['n_deform'])[-10:].tolist()) | set(np.argsort(its)[-12:].tolist())
-    sample |= set(np.random.default_rng(4).choice(len(fps), 24, replace=False).tolist())
+    sample |= set(np.random.default_rng(4).choice(len(fps), 40, replace=False).tolist())
     sample = sorted(sample)
     assert len(sample) >= 64
     orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], [fps[i] for i in sample], scene['dsm_cfg'], nthreads=0)
@@ -804,7 +804,8 @@ def test_failed_dsm_solve_falls_back_and_failed_elliptical_solve_is_an_error(gpu
         _, info = oracle.cvxprog(y, mask, cfg)
         assert recs['status'][k] == _capi.CAND_FALLBACK and info['status'] == 1
         assert recs['n_deform'][k] == info['M'] > 0
-        np.testing.assert_allclose(recs['theta'][k], erecs['theta'][k], rtol=1e-9)
+        # (the elliptical-only batch sums the pixels in another order -- its crop is not sorted by G~ row length --, so its iterates differ in the last digits)
+        np.testing.assert_allclose(recs['theta'][k], erecs['theta'][k], rtol=1e-6)
         assert abs(recs['energy_ell'][k] - erecs['energy'][k]) <= 1e-9 * abs(erecs['energy'][k])
         assert (batch.xi_dev.cpu().numpy() == 0).all()
         np.testing.assert_array_equal(frags[k][1], efrags[k][1])
