@@ -400,8 +400,74 @@ def gen_setcover(scene):
     print('setcover.json')
 
 
+
+# ----------------------------------------------------------------------------------------------
+# Label maps (superdsm/render.py:388-451) and post-processing per-object work (superdsm/postprocess.py:254-337)
+# ----------------------------------------------------------------------------------------------
+class _Obj(robjects.BaseObject):
+    def __init__(self, offset, fragment):
+        self.fg_offset = np.asarray(offset)
+        self.fg_fragment = np.asarray(fragment, bool)
+
+
+def gen_render():
+    import superdsm.render as rrender
+    rng = np.random.default_rng(5)
+    shape = (60, 72)
+    data = {'g_raw': np.zeros(shape)}
+
+    def blob(h, w):
+        rr, cc = np.mgrid[:h, :w]
+        return ((rr - (h - 1) / 2) / (h / 2)) ** 2 + ((cc - (w - 1) / 2) / (w / 2)) ** 2 <= 1
+
+    objs = [((2, 3), blob(9, 12)), ((20, 30), blob(14, 10)), ((40, 5), blob(8, 8)), ((40, 5), blob(8, 8)),     # two coincide exactly
+            ((5, 50), blob(11, 9)), ((34, 44), rng.random((9, 13)) > 0.3), ((55, 60), np.zeros((3, 3), bool))]  # the last one is empty
+    out = dict(shape=np.asarray(shape), n=np.asarray(len(objs)))
+    for k, (off, fr) in enumerate(objs):
+        out[f'o{k}_offset'] = np.asarray(off)
+        out[f'o{k}_fragment'] = np.asarray(fr, np.uint8)
+    cases = dict(plain=dict(), eroded=dict(dilate=-1), dilated=dict(dilate=1), merged=dict(merge_overlap_threshold=0.5))
+    for name, kw in cases.items():
+        out['lab_' + name] = rrender.rasterize_labels(data, [_Obj(o, f) for o, f in objs], **kw).astype(np.int32)
+    save('render', **out)
+
+
+def gen_postprocess(scene):
+    import superdsm.postprocess as rpost
+    g, y, atoms, clusters, seeds = scene
+    rng = np.random.default_rng(9)
+    fg = y > 0
+    lab, n = ndi.label(fg)
+    objs = []
+    for l in range(1, n + 1):
+        m = lab == l
+        if m.sum() < 30:
+            continue
+        off, frag = robjects.extract_foreground_fragment(m)
+        objs.append(_Obj(off, frag))
+    objs = objs[:6]
+    background_mask = np.zeros(g.shape, bool)
+    for o in objs:
+        o.fill_foreground(background_mask)
+    import skimage.morphology as morph
+    background_mask = morph.binary_erosion(~background_mask, morph.disk(5))
+    g_smooth = ndi.gaussian_filter(g, 3)
+    out = dict(g=g, n=np.asarray(len(objs)), background_mask=np.packbits(background_mask.reshape(-1)))
+    for k, o in enumerate(objs):
+        out[f'o{k}_offset'] = np.asarray(o.fg_offset)
+        out[f'o{k}_fragment'] = o.fg_fragment.astype(np.uint8)
+        out[f'o{k}_contrast'] = np.asarray(rpost._compute_contrast(o, g, 5, 5, 1e-4, background_mask))
+        out[f'o{k}_contrast_b'] = np.asarray(rpost._compute_contrast(o, g, 3, 2, 1e-4, background_mask))
+        for tag, (dist, amp, fill) in dict(a=(1, 2, True), b=(2, 1.5, False), c=(0, 2, True)).items():
+            off, frag = rpost._process_mask(o, g_smooth, dist, amp, fill)
+            out[f'o{k}_mask_{tag}_offset'] = np.asarray(off if off is not None else [-1, -1])
+            out[f'o{k}_mask_{tag}_fragment'] = np.asarray(frag if frag is not None else np.zeros((1, 1)), np.uint8)
+        out[f'o{k}_is_glare'] = np.asarray(int(rpost._is_glare(o, g_smooth, 0.5, 5)))
+    save('postprocess', **out)
+
+
 def main():
-    what = set(sys.argv[1:]) or {'preprocess', 'region', 'smoothmat', 'energy', 'optimum', 'config', 'setcover'}
+    what = set(sys.argv[1:]) or {'preprocess', 'region', 'smoothmat', 'energy', 'optimum', 'config', 'setcover', 'render', 'postprocess'}
     scene = make_scene((128, 160), 7, 13, 31, sigma2=10)
     if 'preprocess' in what: gen_preprocess()
     if 'region' in what: gen_region(scene)
@@ -415,6 +481,8 @@ def main():
     if 'setcover' in what:
         scene3 = make_scene((160, 200), 14, 12, 33, sigma2=10)
         gen_setcover(scene3)
+    if 'render' in what: gen_render()
+    if 'postprocess' in what: gen_postprocess(scene)
 
 
 if __name__ == '__main__':

@@ -711,7 +711,10 @@ def test_synthetic4096_matches_oracle(gpu):
             assert recs['status'][k] == _capi.CAND_TRIVIAL
             continue
         tol = 1e-6 * orecs['N'][j] / 1000 + 1e-5 * abs(orecs['energy'][j])
-        assert abs(recs['energy'][k] - orecs['energy'][j]) <= tol, (k, recs['energy'][k], orecs['energy'][j])
+        if orecs['energy'][j] < 1e-3:                      # separable region: psi has no finite minimiser, inf psi = 0; the value is the stopping rule's
+            assert recs['energy'][k] <= orecs['energy'][j] + tol, (k, recs['energy'][k], orecs['energy'][j])
+        else:
+            assert abs(recs['energy'][k] - orecs['energy'][j]) <= tol, (k, recs['energy'][k], orecs['energy'][j])
         assert testing.dice(res['fragments'][k][0], res['fragments'][k][1], orecs['fg_offset'][j], ofrags[j], scene['y'].shape) >= 0.999, k
         assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][j])
 
@@ -805,7 +808,7 @@ def test_failed_dsm_solve_falls_back_and_failed_elliptical_solve_is_an_error(gpu
         assert recs['status'][k] == _capi.CAND_FALLBACK and info['status'] == 1
         assert recs['n_deform'][k] == info['M'] > 0
         # (the elliptical-only batch sums the pixels in another order -- its crop is not sorted by G~ row length --, so its iterates differ in the last digits)
-        np.testing.assert_allclose(recs['theta'][k], erecs['theta'][k], rtol=1e-6)
+        np.testing.assert_allclose(recs['theta'][k], erecs['theta'][k], rtol=0, atol=1e-5 * np.abs(erecs['theta'][k]).max())
         assert abs(recs['energy_ell'][k] - erecs['energy'][k]) <= 1e-9 * abs(erecs['energy'][k])
         assert (batch.xi_dev.cpu().numpy() == 0).all()
         np.testing.assert_array_equal(frags[k][1], efrags[k][1])
