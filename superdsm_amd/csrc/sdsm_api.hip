@@ -112,6 +112,11 @@ extern "C" int sdsm_image_prepare(const double *d_y, const uint8_t *d_y_mask, co
 
 // ---- plan ------------------------------------------------------------------------------------------------
 struct PlanImage { int H, W, n_atoms; };
+
+// Side streams / fork-join events of the solve classes.  A plan borrows a set at its first launch and gives it back when it is
+// destroyed: creating and destroying HIP streams costs milliseconds (hipStreamDestroy synchronises), a reference-style caller
+// builds a plan per batch.  A set carries no state between users (events are recorded before they are waited for).
+struct SideSet { hipStream_t side[2]; hipEvent_t fj[3]; int device; };
 struct sdsm_plan {
     int n = 0;
     std::vector<PlanImage> images;             // one entry for sdsm_plan_create, several for sdsm_plan_create_multi
@@ -134,10 +139,34 @@ struct sdsm_plan {
     mutable uint64_t uploaded_gen = 0;
     mutable const void *uploaded_ws = nullptr;
     // side streams / fork-join events of the solve classes, owned by the plan (created at its first launch)
-    mutable bool sides_ready = false;
-    mutable hipStream_t side[2] = {nullptr, nullptr};
-    mutable hipEvent_t fj[3] = {nullptr, nullptr, nullptr};
+    mutable SideSet *sides = nullptr;
 };
+
+#include <mutex>
+static std::mutex g_pool_mutex;
+static std::vector<SideSet *> g_side_pool;
+
+static hipError_t acquire_sides(const sdsm_plan *p)
+{
+    if (p->sides) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t i = 0; i < g_side_pool.size(); i++) if (g_side_pool[i]->device == dev) {
+            p->sides = g_side_pool[i];
+            g_side_pool.erase(g_side_pool.begin() + i);
+            return hipSuccess;
+        }
+    }
+    SideSet *s = new SideSet();
+    s->device = dev;
+    for (int i = 0; i < 2; i++) if ((e = hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking)) != hipSuccess) { delete s; return e; }
+    for (int i = 0; i < 3; i++) if ((e = hipEventCreateWithFlags(&s->fj[i], hipEventDisableTiming)) != hipSuccess) { delete s; return e; }
+    p->sides = s;
+    return hipSuccess;
+}
 
 static size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -296,9 +325,9 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
 extern "C" void sdsm_plan_destroy(sdsm_plan *plan)
 {
     if (!plan) return;
-    if (plan->sides_ready) {
-        for (int i = 0; i < 2; i++) if (plan->side[i]) (void)hipStreamDestroy(plan->side[i]);
-        for (int i = 0; i < 3; i++) if (plan->fj[i]) (void)hipEventDestroy(plan->fj[i]);
+    if (plan->sides) {                                   // back to the pool (work queued on its streams is ordered by their events)
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        g_side_pool.push_back(plan->sides);
     }
     delete plan;
 }
@@ -433,12 +462,13 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     if ((e = sdsm_launch_setup(P, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch setup");
     if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    if (!p->sides_ready && (p->n_order_c > 0 || p->n_order_d > 0 || p->n_order_w > 0)) {
-        for (int i = 0; i < 2; i++) if ((e = hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
-        for (int i = 0; i < 3; i++) if ((e = hipEventCreateWithFlags(&p->fj[i], hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
-        p->sides_ready = true;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    hipEvent_t *fj = nullptr;
+    if (p->n_order_c > 0 || p->n_order_d > 0 || p->n_order_w > 0) {
+        if ((e = acquire_sides(p)) != hipSuccess) return hipfail(e, "side streams");
+        s1 = p->sides->side[0]; s2 = p->sides->side[1]; fj = p->sides->fj;
     }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, p->side[0], p->side[1], nullptr, const_cast<hipEvent_t *>(p->fj), p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, nullptr, fj, p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }

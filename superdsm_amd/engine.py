@@ -5,6 +5,7 @@ to libsdsm_hip.so.  Nothing here computes on the CPU: if the HIP library or a GP
 fails loudly.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -68,6 +69,10 @@ class DeviceImage:
             _capi.check(L.sdsm_image_prepare(_ptr(self.y), _ptr(self.y_mask), _ptr(self.atoms), self.H, self.W, self.background_margin,
                                              self.n_atoms, _ptr(self.valid), _ptr(stats), _ptr(ws), nbytes, _stream()), 'sdsm_image_prepare')
         self.atom_stats = np.ascontiguousarray(stats.cpu().numpy())       # host copy used by the planner (synchronises)
+
+
+_PINNED = {}                       # (device type, index) -> (records staging, masks staging): pinned, grown on demand, shared
+_PINNED_LOCK = threading.Lock()
 
 
 def fragments_from_masks(records, mask_info, mask_offset, masks, select=None):
@@ -168,7 +173,6 @@ class Batch:
         self.n_pixels = np.zeros(max(self.n, 1), np.int32)
         _capi.check(L.sdsm_plan_describe(self.plan, p(self.mask_info), p(self.mask_offset), p(self.n_pixels)), 'sdsm_plan_describe')
         self.total_pixels = L.sdsm_plan_total_pixels(self.plan)
-        self._host = None
         self._ptrs = tuple((C.c_void_p * ni)(*[getattr(im, k).data_ptr() for im in self.images]) for k in ('y', 'atoms', 'valid'))
         with torch.cuda.device(dev):
             _capi.check(L.sdsm_batch_upload(self.plan, _ptr(self.ws), self.ws_bytes, _stream()), 'sdsm_batch_upload')
@@ -187,15 +191,23 @@ class Batch:
                                                   _ptr(self.records_dev), _ptr(self.masks_dev), _ptr(self.xi_dev), _stream()), 'sdsm_batch_launch_multi')
 
     def download(self):
-        """Records and bit-packed masks to pinned host buffers: two asynchronous copies on the current stream, one
-        synchronisation.  Returns (records structured array, masks uint8 array) -- views, valid until the next download."""
-        if self._host is None:
-            self._host = (torch.empty(self.records_dev.numel(), dtype=torch.uint8).pin_memory(), torch.empty(self.masks_dev.numel(), dtype=torch.uint8).pin_memory())
-        with torch.cuda.device(self.image.device):
-            self._host[0].copy_(self.records_dev, non_blocking=True)
-            self._host[1].copy_(self.masks_dev, non_blocking=True)
+        """Records and bit-packed masks to pinned host staging buffers: two asynchronous copies on the current stream, one
+        synchronisation.  Returns (records structured array, masks uint8 array) -- VIEWS of the staging buffers, which are shared
+        by all batches of the device and valid until the next download (copy what must live longer)."""
+        dev = self.image.device
+        key = (dev.type, dev.index)
+        with _PINNED_LOCK:
+            cur = _PINNED.get(key)
+            need = (self.records_dev.numel(), self.masks_dev.numel())
+            if cur is None or cur[0].numel() < need[0] or cur[1].numel() < need[1]:
+                grow = lambda old, n: max(n, 2 * old) if old else max(n, 1 << 16)      # page-locking memory costs milliseconds: amortised
+                cur = tuple(torch.empty(grow(0 if cur is None else cur[k].numel(), need[k]), dtype=torch.uint8).pin_memory() for k in range(2))
+                _PINNED[key] = cur
+        with torch.cuda.device(dev):
+            cur[0][:need[0]].copy_(self.records_dev, non_blocking=True)
+            cur[1][:need[1]].copy_(self.masks_dev, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-        return self._host[0].numpy().view(_capi.RECORD_DTYPE)[:self.n], self._host[1].numpy()
+        return cur[0].numpy()[:need[0]].view(_capi.RECORD_DTYPE)[:self.n], cur[1].numpy()[:need[1]]
 
     def records(self):
         return self.records_dev.cpu().numpy().view(_capi.RECORD_DTYPE)[:self.n].copy()

@@ -21,24 +21,28 @@ def _greedy_cover(objects, beta):
 
 
 def _merge_phase(objects, accepted, beta):
-    """Merge phase: a not-yet-accepted object replaces the accepted objects it fully contains if that is cheaper."""
+    """Merge phase: a not-yet-accepted object replaces the accepted objects it fully contains if that is cheaper.
+    (Same decisions as minsetcover.py:4-21; membership by identity sets and subset / disjointness tests instead of building the
+    intersections -- this loop is the host-side hot spot of the stage once the solves run on the GPU.)"""
     replaced = 0
-    cost = lambda c: c.energy + beta
-    for new in sorted((c for c in objects if c not in accepted), key=cost):
+    taken = {id(c) for c in accepted}
+    for new in sorted((c for c in objects if id(c) not in taken), key=lambda c: c.energy + beta):
+        nf = new.footprint
         inside = []
         for c in accepted:
-            common = len(c.footprint & new.footprint)
-            if common == 0:
+            cf = c.footprint
+            if cf.isdisjoint(nf):
                 continue
-            if common < len(c.footprint):
+            if not cf <= nf:
                 inside = None                       # partial overlap: not a valid replacement
                 break
             inside.append(c)
         if inside is None:
             continue
-        if cost(new) < sum(cost(c) for c in inside):
+        if new.energy + beta < sum(c.energy + beta for c in inside):
             replaced += len(inside)
-            accepted = [c for c in accepted if c not in inside] + [new]
+            gone = {id(c) for c in inside}
+            accepted = [c for c in accepted if id(c) not in gone] + [new]
     return accepted, replaced
 
 
