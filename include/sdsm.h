@@ -173,6 +173,32 @@ int sdsm_plan_layout(const sdsm_plan *plan, int64_t *out);
 int sdsm_plan_set_latency_mode(sdsm_plan *plan, int mode);
 int sdsm_plan_xi_offsets(const sdsm_plan *plan, int64_t *xi_offset);
 
+/* ---- post-processing, per-object work (superdsm/postprocess.py:254-337) ------------------------------------- */
+/* One object's results.  64 bytes, written by the device. */
+typedef struct {
+    double contrast;        /* (interior_mean + eps) / (exterior_mean + eps)                     postprocess.py:254-266 */
+    double interior_mean;   /* mean of g / g.std() over the object's mask */
+    double exterior_mean;   /* weighted mean over the exterior neighbourhood */
+    double fg_mean, fg_std; /* mean / population std of the smoothed intensities over the mask   postprocess.py:323-325 */
+    int32_t area;           /* mask pixels */
+    int32_t status;         /* 0 ok, 1 boundary list too long and no pool slot, 2 empty mask, 3 ok, no refinement requested */
+    int32_t r0, c0, h, w;   /* bounding box of the refined mask (h == 0: empty) */
+} sdsm_post_record;
+/* d_g: raw intensities (H*W float64); d_gs: Gaussian-smoothed intensities used by the mask refinement (postprocess.py:165);
+ * d_bg: background_mask uint8 (postprocess.py:152-155).  Objects: d_boxes n*4 int32 (r0, c0, h, w of each fragment), fragments
+ * bit-packed (row-major, LSB first in uint32 words) at d_bits + d_bits_off[i] (in words).  Outputs: d_out n records; the refined
+ * masks over the windows box +- max_distance (clamped to the image), bit-packed at d_new_bits + d_new_off[i] (only written when
+ * max_distance > 0 and stdamp > 0; hole filling stays on the host).  d_boundary_pool / d_bpool_off (may be NULL): global
+ * boundary lists for objects whose mask boundary exceeds 12288 pixels (d_bpool_off[i] < 0: none).  inv_gstd = 1 / g.std(). */
+int sdsm_post_objects(const double *d_g, const double *d_gs, const uint8_t *d_bg, int H, int W, int n, const int32_t *d_boxes,
+                      const int64_t *d_bits_off, const uint32_t *d_bits, const int64_t *d_new_off, uint32_t *d_new_bits,
+                      uint32_t *d_boundary_pool, const int64_t *d_bpool_off, double exterior_scale, double exterior_offset,
+                      double contrast_epsilon, double inv_gstd, int max_distance, double stdamp, sdsm_post_record *d_out, void *stream);
+/* Separable Gaussian filter with SciPy's defaults (mode 'reflect', truncate 4): the smoothing of postprocess.py:165-166 and the
+ * building block of sdsm_preprocess. */
+size_t sdsm_gaussian_workspace_bytes(int H, int W, double sigma);
+int sdsm_gaussian_filter(const double *d_in, int H, int W, double sigma, double *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* Host helper (no device access): the foreground fragments (objects.py:148-174) of a batch out of the downloaded records and
  * bit-packed masks, one byte per pixel: fragment i (fg_h x fg_w, row-major) at out + out_offset[i]; candidates without a
  * foreground get the single byte 0 ([[False]], objects.py:172-174).  Returns the bytes written -- or needed, when out == NULL. */

@@ -31,6 +31,9 @@ RECORD_DTYPE = np.dtype([
     ('iters_ell', 'i4'), ('iters_dsm', 'i4'), ('evals_value', 'i4'), ('evals_full', 'i4'),
     ('on_boundary', 'i4'), ('fg_r0', 'i4'), ('fg_c0', 'i4'), ('fg_h', 'i4'), ('fg_w', 'i4'), ('n_positive', 'i4'), ('n_negative', 'i4'), ('reserved', 'i4')])
 assert RECORD_DTYPE.itemsize == 128
+POST_RECORD_DTYPE = np.dtype([('contrast', 'f8'), ('interior_mean', 'f8'), ('exterior_mean', 'f8'), ('fg_mean', 'f8'), ('fg_std', 'f8'),
+                              ('area', 'i4'), ('status', 'i4'), ('r0', 'i4'), ('c0', 'i4'), ('h', 'i4'), ('w', 'i4')])
+assert POST_RECORD_DTYPE.itemsize == 64
 
 # every entry point of include/sdsm.h: name -> (restype, argtypes)
 _vp, _i32, _f64, _sz, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_int64
@@ -59,6 +62,9 @@ SYMBOLS = {
     'sdsm_plan_xi_offsets': (_i32, [_vp, _vp]),
     'sdsm_plan_layout': (_i32, [_vp, _vp]),
     'sdsm_plan_set_latency_mode': (_i32, [_vp, _i32]),
+    'sdsm_post_objects': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _f64, _vp, _vp]),
+    'sdsm_gaussian_workspace_bytes': (_sz, [_i32, _i32, _f64]),
+    'sdsm_gaussian_filter': (_i32, [_vp, _i32, _i32, _f64, _vp, _vp, _sz, _vp]),
     'sdsm_unpack_fragments': (_i64, [_vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     'sdsm_plan_eval_param_count': (_i64, [_vp]),
     'sdsm_plan_eval_out_count': (_i64, [_vp]),

@@ -530,3 +530,35 @@ extern "C" int64_t sdsm_unpack_fragments(const sdsm_record *records, const int32
     }
     return pos;
 }
+
+// ---- post-processing, per-object work ----------------------------------------------------------------------------------------
+extern "C" hipError_t sdsm_launch_post(const double *g, const double *gs, const uint8_t *bg, int H, int W, int n, const int32_t *boxes,
+                                       const int64_t *bits_off, const uint32_t *bits, const int64_t *new_off, uint32_t *new_bits,
+                                       uint32_t *boundary_pool, const int64_t *bpool_off, double exterior_scale, double exterior_offset,
+                                       double contrast_epsilon, double inv_gstd, int max_distance, double stdamp, sdsm_post_record *out, hipStream_t stream);
+extern "C" hipError_t sdsm_gaussian_filter_impl(const double *d_in, int H, int W, double sigma, double *d_out, void *d_ws, hipStream_t stream);
+extern "C" size_t sdsm_gaussian_workspace_bytes(int H, int W, double sigma);
+
+extern "C" int sdsm_post_objects(const double *d_g, const double *d_gs, const uint8_t *d_bg, int H, int W, int n, const int32_t *d_boxes,
+                                 const int64_t *d_bits_off, const uint32_t *d_bits, const int64_t *d_new_off, uint32_t *d_new_bits,
+                                 uint32_t *d_boundary_pool, const int64_t *d_bpool_off, double exterior_scale, double exterior_offset,
+                                 double contrast_epsilon, double inv_gstd, int max_distance, double stdamp, sdsm_post_record *d_out, void *stream)
+{
+    if (n < 0 || H < 1 || W < 1 || H > 65535 || W > 65535) return fail(SDSM_ERR_ARGUMENT, "sdsm_post_objects: bad shape");
+    if (n == 0) return SDSM_OK;
+    if (!d_g || !d_gs || !d_bg || !d_boxes || !d_bits_off || !d_bits || !d_out) return fail(SDSM_ERR_ARGUMENT, "sdsm_post_objects: null argument");
+    if (!(exterior_scale > 0) || !(exterior_offset >= 0) || max_distance < 0 || max_distance > 16) return fail(SDSM_ERR_ARGUMENT, "sdsm_post_objects: exterior_scale > 0, exterior_offset >= 0, 0 <= max_distance <= 16 required");
+    if (max_distance > 0 && stdamp > 0 && (!d_new_off || !d_new_bits)) return fail(SDSM_ERR_ARGUMENT, "sdsm_post_objects: refinement needs the output mask buffers");
+    if ((d_boundary_pool == nullptr) != (d_bpool_off == nullptr)) return fail(SDSM_ERR_ARGUMENT, "sdsm_post_objects: boundary pool and its offsets go together");
+    hipError_t e = sdsm_launch_post(d_g, d_gs, d_bg, H, W, n, d_boxes, d_bits_off, d_bits, d_new_off, d_new_bits, d_boundary_pool, d_bpool_off,
+                                    exterior_scale, exterior_offset, contrast_epsilon, inv_gstd, max_distance, stdamp, d_out, (hipStream_t)stream);
+    return e == hipSuccess ? SDSM_OK : hipfail(e, "sdsm_post_objects");
+}
+
+extern "C" int sdsm_gaussian_filter(const double *d_in, int H, int W, double sigma, double *d_out, void *d_ws, size_t ws_bytes, void *stream)
+{
+    if (!d_in || !d_out || !d_ws || H < 1 || W < 1 || !(sigma > 0)) return fail(SDSM_ERR_ARGUMENT, "sdsm_gaussian_filter: bad argument");
+    if (ws_bytes < sdsm_gaussian_workspace_bytes(H, W, sigma)) return fail(SDSM_ERR_WORKSPACE, "sdsm_gaussian_filter: workspace too small");
+    hipError_t e = sdsm_gaussian_filter_impl(d_in, H, W, sigma, d_out, d_ws, (hipStream_t)stream);
+    return e == hipSuccess ? SDSM_OK : hipfail(e, "sdsm_gaussian_filter");
+}

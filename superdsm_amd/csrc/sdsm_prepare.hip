@@ -6,6 +6,7 @@
 //                                         truncate=4; symmetric correlate1d association order)
 //   EDT(y <= 0) <= background_margin      superdsm/objects.py:126-127   (candidate independent)
 #include "sdsm_common.h"
+#include <vector>
 
 #pragma clang fp contract(off)   // keep SciPy's / numpy's unfused association (bit-level parity of y)
 
@@ -340,4 +341,22 @@ extern "C" hipError_t sdsm_preprocess_impl(const double *d_g, int H, int W, doub
     hipLaunchKernelGGL(k_combine, g1, b, 0, stream, (const double *)tmpA, (const double *)off, (const double *)offc, (const double *)tmpB,
                        n, use_clip, lower_clip_mean, (const double *)scal, (const int *)any, sigma2, d_y);
     return hipGetLastError();
+}
+
+// ---- plain Gaussian filter (scipy.ndimage.gaussian_filter defaults), for the smoothed images of the post-processing stage ----
+extern "C" size_t sdsm_gaussian_workspace_bytes(int H, int W, double sigma)
+{
+    return align_up((size_t)H * W * 8, 256) + align_up((size_t)(2 * gauss_radius(sigma) + 1) * 8, 256);
+}
+
+extern "C" hipError_t sdsm_gaussian_filter_impl(const double *d_in, int H, int W, double sigma, double *d_out, void *d_ws, hipStream_t stream)
+{
+    const int R = gauss_radius(sigma);
+    double *tmp = (double *)d_ws;
+    double *w = (double *)((uint8_t *)d_ws + align_up((size_t)H * W * 8, 256));
+    std::vector<double> hw(2 * R + 1);
+    sdsm_gauss_kernel_host(sigma, R, hw.data());
+    hipError_t e = hipMemcpyAsync(w, hw.data(), hw.size() * 8, hipMemcpyHostToDevice, stream);   // (pageable source: staged before the call returns)
+    if (e != hipSuccess) return e;
+    return gauss2d(d_in, H, W, w, R, tmp, d_out, stream);
 }

@@ -1046,3 +1046,86 @@ def test_launch_refuses_a_workspace_uploaded_before_a_layout_change(gpu, tmp_pat
     atoms2 = scene['atoms'].copy()
     atoms2[atoms2 == 1] = 2
     assert objects.device_image(yi, atoms2, 8) is not d0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# post-processing, per-object work (superdsm/postprocess.py:254-337)
+# ---------------------------------------------------------------------------------------------------------
+class _Frag:
+    def __init__(self, off, frag):
+        self.fg_offset, self.fg_fragment = np.asarray(off), np.asarray(frag, bool)
+
+    def fill_foreground(self, out, value=True):
+        h, w = self.fg_fragment.shape
+        out[self.fg_offset[0]:self.fg_offset[0] + h, self.fg_offset[1]:self.fg_offset[1] + w] = value * self.fg_fragment
+
+
+def test_postprocess_objects_match_reference_fixtures(gpu):
+    """Contrast response and refined masks of sdsm_post_objects against the outputs of the reference's own _compute_contrast /
+    _process_mask (tests/golden/postprocess.npz), for two parameter sets each."""
+    from superdsm_amd import postprocess
+    d = np.load(os.path.join(G, 'postprocess.npz'))
+    g = d['g']
+    bg = np.unpackbits(d['background_mask'])[:g.size].reshape(g.shape).astype(bool)
+    objs = [_Frag(d[f'o{k}_offset'], d[f'o{k}_fragment']) for k in range(int(d['n']))]
+    g_dev = gpu.as_tensor(g).cuda()
+    gs = postprocess.gaussian_filter_gpu(g_dev, 3)
+    import scipy.ndimage as ndi
+    np.testing.assert_allclose(gs.cpu().numpy(), ndi.gaussian_filter(g, 3), rtol=0, atol=1e-15)
+    for key, (scale, offset), tag, (dist, amp, fill) in (('contrast', (5, 5), 'a', (1, 2, True)), ('contrast_b', (3, 2), 'b', (2, 1.5, False))):
+        recs, refined = postprocess.process_objects_gpu(objs, g_dev, gs, bg, scale, offset, 1e-4, dist, amp)
+        for k in range(len(objs)):
+            assert abs(recs['contrast'][k] - float(d[f'o{k}_{key}'])) <= 1e-10 * abs(float(d[f'o{k}_{key}'])), (key, k)
+            off, frag = refined[k]
+            if fill:
+                frag = ndi.binary_fill_holes(frag)
+            np.testing.assert_array_equal(off, d[f'o{k}_mask_{tag}_offset'])
+            np.testing.assert_array_equal(frag, d[f'o{k}_mask_{tag}_fragment'].astype(bool))
+            assert recs['area'][k] == objs[k].fg_fragment.sum()
+
+
+def test_postprocess_stage_on_a_segmented_scene_matches_oracle(gpu):
+    """The whole downstream chain on the BBBC039-like scene: global energy minimisation -> Postprocessing stage -> label map ->
+    regression rows; the per-object numbers against the full-image CPU restatement (oracle/postprocess_oracle.py), incl. an
+    object whose boundary list lives in global memory."""
+    import scipy.ndimage as ndi
+    from oracle import postprocess_oracle as po
+    from superdsm_amd import config, globalenergymin, postprocess, render, testing
+    scene = testing.make_scene('bbbc039_like', max_size=2)
+    data = dict(g_raw=scene['g'], y=scene['y'], y_mask=np.ones(scene['y'].shape, bool), atoms=scene['atoms'], adjacencies=scene['adjacencies'], dsm_cfg=scene['dsm_cfg'])
+    cfg = config.Config({'global-energy-minimization': {'beta': 150.0, 'pruning': 'isbi24'}, 'postprocess': {'min_contrast': 1.2}})
+    globalenergymin.GlobalEnergyMinimization()(data, cfg, out='muted')
+    stage = postprocess.Postprocessing()
+    stage(data, cfg, out='muted')
+    sol = list(data['cover'].solution)
+    post = data['postprocessed_objects']
+    assert 0 < len(post) <= len(sol)
+    g = scene['g']
+    bg = po.background_mask(g.shape, [(o.fg_offset, o.fg_fragment) for o in sol], 5)
+    gs = ndi.gaussian_filter(g, 3)
+    recs = stage.last_records
+    kept = {id(p.original): p for p in post}
+    for k, o in enumerate(sol):
+        want = po.compute_contrast(o.fg_offset, o.fg_fragment, g, 5, 5, 1e-4, bg)
+        assert abs(recs['contrast'][k] - want) <= 1e-9 * abs(want), k
+        if id(o) in kept:
+            off, frag = po.process_mask(o.fg_offset, o.fg_fragment, gs, 1, 2, True)
+            np.testing.assert_array_equal(kept[id(o)].fg_offset, off)
+            np.testing.assert_array_equal(kept[id(o)].fg_fragment, frag)
+            assert abs(o.energy / o.cvxprog_region_size) <= 0.2 and want >= 1.2
+    labels = render.rasterize_labels(data)
+    rows = render.label_map_rows(labels)
+    assert len(rows) == len(post) == labels.max()
+    assert render.regression_agreement(rows, rows)['matched_fraction'] == 1.0
+    # a very large object: boundary list in global memory
+    rr, cc = np.mgrid[:520, :696]
+    big = _Frag((40, 60), ((rr[40:440, 60:560] - 240) / 200.0) ** 2 + ((cc[40:440, 60:560] - 310) / 250.0) ** 2 <= 1)
+    assert big.fg_fragment.sum() > 12288
+    g_dev = gpu.as_tensor(g).cuda()
+    bgb = po.background_mask(g.shape, [(big.fg_offset, big.fg_fragment)], 5)
+    r2, f2 = postprocess.process_objects_gpu([big], g_dev, postprocess.gaussian_filter_gpu(g_dev, 3), bgb, 5, 5, 1e-4, 1, 2)
+    want = po.compute_contrast(big.fg_offset, big.fg_fragment, g, 5, 5, 1e-4, bgb)
+    assert abs(r2['contrast'][0] - want) <= 1e-9 * abs(want)
+    off, frag = po.process_mask(big.fg_offset, big.fg_fragment, gs, 1, 2, False)
+    np.testing.assert_array_equal(f2[0][0], off)
+    np.testing.assert_array_equal(f2[0][1], frag)

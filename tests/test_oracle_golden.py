@@ -144,3 +144,59 @@ def test_tight_optima_and_mask_tail(tag):
             assert recs['energy'][k] <= psi_ref + tol
         # moment-based initialisation (objects.py:287-296)
         np.testing.assert_allclose(oracle.moment_init(y, mask), d[f'c{k}_moment_init'], rtol=1e-9)
+
+
+def test_postprocess_oracle_matches_reference_fixtures():
+    """Contrast response, mask refinement and glare test of the reference (postprocess.py:254-337) on 6 objects."""
+    from oracle import postprocess_oracle as po
+    d = np.load(os.path.join(G, 'postprocess.npz'))
+    g = d['g']
+    bg = np.unpackbits(d['background_mask'])[:g.size].reshape(g.shape).astype(bool)
+    objs = [(d[f'o{k}_offset'], d[f'o{k}_fragment'].astype(bool)) for k in range(int(d['n']))]
+    np.testing.assert_array_equal(po.background_mask(g.shape, objs, 5), bg)
+    gs = scipy_gauss(g, 3)
+    for k, (off, frag) in enumerate(objs):
+        np.testing.assert_allclose(po.compute_contrast(off, frag, g, 5, 5, 1e-4, bg), float(d[f'o{k}_contrast']), rtol=1e-12)
+        np.testing.assert_allclose(po.compute_contrast(off, frag, g, 3, 2, 1e-4, bg), float(d[f'o{k}_contrast_b']), rtol=1e-12)
+        for tag, (dist, amp, fill) in dict(a=(1, 2, True), b=(2, 1.5, False), c=(0, 2, True)).items():
+            o2, f2 = po.process_mask(off, frag, gs, dist, amp, fill)
+            np.testing.assert_array_equal(o2, d[f'o{k}_mask_{tag}_offset'])
+            np.testing.assert_array_equal(f2, d[f'o{k}_mask_{tag}_fragment'].astype(bool))
+        assert int(po.is_glare(off, frag, gs, 0.5, 5)) == int(d[f'o{k}_is_glare'])
+
+
+def scipy_gauss(g, sigma):
+    import scipy.ndimage as ndi
+    return ndi.gaussian_filter(g, sigma)
+
+
+def test_label_maps_match_reference_fixtures():
+    """rasterize_labels (render.py:388-451) on disjoint, eroded / dilated, merged and exactly coinciding objects, and the
+    regression rows of tests/regression/validate.py:31-36 on the result."""
+    from superdsm_amd import objects, render
+    d = np.load(os.path.join(G, 'render.npz'))
+    shape = tuple(int(v) for v in d['shape'])
+
+    class Obj(objects.BaseObject):
+        def __init__(self, off, frag):
+            self.fg_offset, self.fg_fragment = np.asarray(off), np.asarray(frag, bool)
+
+    objs = [Obj(d[f'o{k}_offset'], d[f'o{k}_fragment']) for k in range(int(d['n']))]
+    data = {'g_raw': np.zeros(shape)}
+    for name, kw in dict(plain={}, eroded=dict(dilate=-1), dilated=dict(dilate=1), merged=dict(merge_overlap_threshold=0.5)).items():
+        got = render.rasterize_labels(data, objs, **kw)
+        np.testing.assert_array_equal(got, d['lab_' + name])
+    lab = render.rasterize_labels(data, objs)
+    rows = render.label_map_rows(lab)
+    assert len(rows) == len(np.unique(lab)) - 1 and all(isinstance(v, str) for row in rows for v in row)
+    import scipy.ndimage as ndi
+    for area, cx, cy in rows:
+        l = lab[int(round(float(cy))), int(round(float(cx)))]
+        assert l > 0 and int(area) == (lab == l).sum()
+    missing, spurious = render.compare_rows(rows, rows[1:] + [('1', '0.0', '0.0')])
+    assert spurious == {rows[0]} and missing == {('1', '0.0', '0.0')}
+    # overlapping objects: the overlap goes to one of the two, nothing is lost, wrap-around of a negative background label
+    a, b = Obj((2, 2), np.ones((10, 12), bool)), Obj((6, 8), np.ones((12, 10), bool))
+    lab2 = render.rasterize_labels(data, [a, b])
+    assert set(np.unique(lab2).tolist()) == {0, 1, 2} and (lab2 > 0).sum() == 120 + 120 - 36
+    assert render.rasterize_labels(data, [a], background_label=-1)[0, 0] == 65535

@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 outputs merged under gpurun_out/ into the small committed summaries under profiles/.
-usage: python tools/summarize_profiles.py r01"""
+usage: python tools/summarize_profiles.py r02 [workload] [images per launch]
+The summary records the hash of the kernel sources it was measured on: bench.py reports its traffic figure only while that
+hash matches the sources that are running."""
 import collections
 import csv
 import glob
 import json
 import os
+import hashlib
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+workload = sys.argv[2] if len(sys.argv) > 2 else 'bbbc039_like'
+images = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(os.path.join(root, 'profiles'), exist_ok=True)
 stats = glob.glob(os.path.join(root, 'gpurun_out', f'{tag}_trace', '*', '*kernel_stats.csv'))
@@ -35,8 +40,18 @@ fetch = per_kernel(f'{tag}_fetch', 'FETCH_SIZE')
 write = per_kernel(f'{tag}_write', 'WRITE_SIZE')
 solve_fetch = sum(v['avg_per_dispatch_KB'] for k, v in fetch.items() if 'sdsm_k_solve' in k) * 1024
 solve_write = sum(v['avg_per_dispatch_KB'] for k, v in write.items() if 'sdsm_k_solve' in k) * 1024
+def source_hash():
+    h = hashlib.sha1()
+    d = os.path.join(root, 'superdsm_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 out = dict(
-    note=('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --inflight 1).  Counters are in KB.  '
+    source_hash=source_hash(), workload=workload, images_per_launch=images,
+    note=('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --no-cpu --no-extras --steps 6 --warmup 2 --repeats 2`.  Counters are in KB.  '
           'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a WIDE (16 B/lane) coalesced stream; this kernel '
           'reads 2-8 B per lane (u16 / f32 / f64), a width the guide lists as uncalibrated, so the raw value is kept and the '
           'x2 figure is given as an upper bound.'),
