@@ -46,7 +46,7 @@ def background_mask(shape, objects, exterior_offset):
     """postprocess.py:152-155; objects: list of (offset, fragment)."""
     fg = np.zeros(shape, bool)
     for off, frag in objects:
-        fg[off[0]:off[0] + frag.shape[0], off[1]:off[1] + frag.shape[1]] |= frag      # fill_foreground writes, later objects win: same union for disjoint objects
+        fg[off[0]:off[0] + frag.shape[0], off[1]:off[1] + frag.shape[1]] = frag       # fill_foreground ASSIGNS the whole box (objects.py:44-47): a later object's box overwrites
     return binary_erosion(~fg, disk(exterior_offset))
 
 
