@@ -198,6 +198,12 @@ int sdsm_post_objects(const double *d_g, const double *d_gs, const uint8_t *d_bg
  * building block of sdsm_preprocess. */
 size_t sdsm_gaussian_workspace_bytes(int H, int W, double sigma);
 int sdsm_gaussian_filter(const double *d_in, int H, int W, double sigma, double *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+/* The same with caller-given SYMMETRIC weights per axis (HOST arrays of 2 R + 1 doubles): axis 0 with h_w0, then axis 1 with h_w1,
+ * 'reflect' boundary -- e.g. the derivative-of-Gaussian filters of scipy.ndimage.gaussian_laplace used by the scale estimation
+ * (superdsm/automation.py:52). */
+size_t sdsm_separable_workspace_bytes(int H, int W, int R0, int R1);
+int sdsm_separable_filter(const double *d_in, int H, int W, const double *h_w0, int R0, const double *h_w1, int R1,
+                          double *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* Host helper (no device access): the foreground fragments (objects.py:148-174) of a batch out of the downloaded records and
  * bit-packed masks, one byte per pixel: fragment i (fg_h x fg_w, row-major) at out + out_offset[i]; candidates without a

@@ -562,3 +562,17 @@ extern "C" int sdsm_gaussian_filter(const double *d_in, int H, int W, double sig
     hipError_t e = sdsm_gaussian_filter_impl(d_in, H, W, sigma, d_out, d_ws, (hipStream_t)stream);
     return e == hipSuccess ? SDSM_OK : hipfail(e, "sdsm_gaussian_filter");
 }
+
+extern "C" size_t sdsm_separable_workspace_bytes(int H, int W, int R0, int R1);
+extern "C" hipError_t sdsm_separable_filter_impl(const double *d_in, int H, int W, const double *h_w0, int R0, const double *h_w1, int R1,
+                                                 double *d_out, void *d_ws, hipStream_t stream);
+extern "C" int sdsm_separable_filter(const double *d_in, int H, int W, const double *h_w0, int R0, const double *h_w1, int R1,
+                                     double *d_out, void *d_ws, size_t ws_bytes, void *stream)
+{
+    if (!d_in || !d_out || !d_ws || !h_w0 || !h_w1 || H < 1 || W < 1 || R0 < 0 || R1 < 0) return fail(SDSM_ERR_ARGUMENT, "sdsm_separable_filter: bad argument");
+    for (int j = 1; j <= R0; j++) if (h_w0[R0 - j] != h_w0[R0 + j]) return fail(SDSM_ERR_ARGUMENT, "sdsm_separable_filter: weights must be symmetric");
+    for (int j = 1; j <= R1; j++) if (h_w1[R1 - j] != h_w1[R1 + j]) return fail(SDSM_ERR_ARGUMENT, "sdsm_separable_filter: weights must be symmetric");
+    if (ws_bytes < sdsm_separable_workspace_bytes(H, W, R0, R1)) return fail(SDSM_ERR_WORKSPACE, "sdsm_separable_filter: workspace too small");
+    hipError_t e = sdsm_separable_filter_impl(d_in, H, W, h_w0, R0, h_w1, R1, d_out, d_ws, (hipStream_t)stream);
+    return e == hipSuccess ? SDSM_OK : hipfail(e, "sdsm_separable_filter (a filter radius beyond ~2500 does not fit the LDS tiles)");
+}

@@ -170,21 +170,23 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const double *__restrict__ i
 }
 
 // axis 0: one workgroup = 32 columns x 64 rows (+ halo rows) staged in LDS; thread = (column, 8 rows)
-#define GC_COLS 32
+#define GC_COLS_MAX 32
 #define GC_ROWS 64
+template <int GC_COLS>
 __global__ __launch_bounds__(256) void k_gauss_cols(const double *__restrict__ in, int H, int W, const double *__restrict__ w, int R, double *__restrict__ out)
 {
     double *lds = (double *)sdsm_dyn_lds;
     const int c0 = blockIdx.x * GC_COLS, r0 = blockIdx.y * GC_ROWS, tid = threadIdx.x;
-    const int lc = tid % GC_COLS, lr = tid / GC_COLS;          // 32 x 8
+    constexpr int LR = 256 / GC_COLS;                          // 32 x 8 (or 8 x 32 for very long filters: the tile must fit the LDS)
+    const int lc = tid % GC_COLS, lr = tid / GC_COLS;
     const int rows = GC_ROWS + 2 * R;
     const int c = c0 + lc;
     const int cs = c < W ? c : W - 1;
-    for (int i = lr; i < rows; i += 8) lds[i * GC_COLS + lc] = in[(size_t)reflect_idx(r0 - R + i, H) * W + cs];
+    for (int i = lr; i < rows; i += LR) lds[i * GC_COLS + lc] = in[(size_t)reflect_idx(r0 - R + i, H) * W + cs];
     __syncthreads();
     if (c >= W) return;
-    for (int k = 0; k < GC_ROWS / 8; k++) {
-        int rl = lr + 8 * k, r = r0 + rl;
+    for (int k = 0; k < GC_ROWS / LR; k++) {
+        int rl = lr + LR * k, r = r0 + rl;
         if (r >= H) break;
         const double *ctr = lds + (rl + R) * GC_COLS + lc;
         double acc = ctr[0] * w[R];
@@ -279,15 +281,30 @@ extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w)
     for (int i = 0; i <= 2 * radius; i++) w[i] = w[i] / s;
 }
 
+// axis 0 with weights (d_w0, R0) into tmp, then axis 1 with (d_w1, R1) into out: scipy.ndimage's order of the axes
+static hipError_t separable2d(const double *in, int H, int W, const double *d_w0, int R0, const double *d_w1, int R1, double *tmp, double *out, hipStream_t stream)
+{
+    size_t lds_r = (size_t)(256 + 2 * R1) * 8;
+    if (lds_r > 160 * 1024 - 1024) return hipErrorInvalidValue;
+    hipError_t e;
+    size_t lds_c = (size_t)(GC_ROWS + 2 * R0) * 32 * 8;
+    if (lds_c <= 160 * 1024 - 1024) {
+        if ((e = hipFuncSetAttribute((const void *)k_gauss_cols<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gauss_cols<32>, dim3((W + 31) / 32, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w0, R0, tmp);
+    } else {
+        lds_c = (size_t)(GC_ROWS + 2 * R0) * 8 * 8;
+        if (lds_c > 160 * 1024 - 1024) return hipErrorInvalidValue;
+        if ((e = hipFuncSetAttribute((const void *)k_gauss_cols<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gauss_cols<8>, dim3((W + 7) / 8, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w0, R0, tmp);
+    }
+    if ((e = hipFuncSetAttribute((const void *)k_gauss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gauss_rows, dim3((W + 255) / 256, H), dim3(256), lds_r, stream, (const double *)tmp, H, W, d_w1, R1, out);
+    return hipGetLastError();
+}
+
 static hipError_t gauss2d(const double *in, int H, int W, const double *d_w, int R, double *tmp, double *out, hipStream_t stream)
 {
-    size_t lds_c = (size_t)(GC_ROWS + 2 * R) * GC_COLS * 8, lds_r = (size_t)(256 + 2 * R) * 8;
-    if (lds_c > 160 * 1024 - 1024) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void *)k_gauss_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gauss_cols, dim3((W + GC_COLS - 1) / GC_COLS, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w, R, tmp);
-    hipLaunchKernelGGL(k_gauss_rows, dim3((W + 255) / 256, H), dim3(256), lds_r, stream, (const double *)tmp, H, W, d_w, R, out);
-    return hipGetLastError();
+    return separable2d(in, H, W, d_w, R, d_w, R, tmp, out, stream);
 }
 
 extern "C" hipError_t sdsm_preprocess_impl(const double *d_g, int H, int W, double sigma1, double sigma2, double offset_clip,
@@ -359,4 +376,22 @@ extern "C" hipError_t sdsm_gaussian_filter_impl(const double *d_in, int H, int W
     hipError_t e = hipMemcpyAsync(w, hw.data(), hw.size() * 8, hipMemcpyHostToDevice, stream);   // (pageable source: staged before the call returns)
     if (e != hipSuccess) return e;
     return gauss2d(d_in, H, W, w, R, tmp, d_out, stream);
+}
+
+// ---- separable filter with caller-given SYMMETRIC weights per axis (host arrays of 2 R + 1 doubles, centre at R): the
+//      derivative-of-Gaussian filters of scipy.ndimage.gaussian_laplace in the scale estimation (superdsm/automation.py:52) ----
+extern "C" size_t sdsm_separable_workspace_bytes(int H, int W, int R0, int R1)
+{
+    return align_up((size_t)H * W * 8, 256) + align_up((size_t)(2 * R0 + 1 + 2 * R1 + 1) * 8, 256);
+}
+
+extern "C" hipError_t sdsm_separable_filter_impl(const double *d_in, int H, int W, const double *h_w0, int R0, const double *h_w1, int R1,
+                                                 double *d_out, void *d_ws, hipStream_t stream)
+{
+    double *tmp = (double *)d_ws;
+    double *w0 = (double *)((uint8_t *)d_ws + align_up((size_t)H * W * 8, 256)), *w1 = w0 + (2 * R0 + 1);
+    hipError_t e = hipMemcpyAsync(w0, h_w0, (size_t)(2 * R0 + 1) * 8, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(w1, h_w1, (size_t)(2 * R1 + 1) * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    return separable2d(d_in, H, W, w0, R0, w1, R1, tmp, d_out, stream);
 }

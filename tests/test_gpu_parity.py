@@ -1129,3 +1129,40 @@ def test_postprocess_stage_on_a_segmented_scene_matches_oracle(gpu):
     off, frag = po.process_mask(big.fg_offset, big.fg_fragment, gs, 1, 2, False)
     np.testing.assert_array_equal(f2[0][0], off)
     np.testing.assert_array_equal(f2[0][1], frag)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# scale estimation (superdsm/automation.py:41-68)
+# ---------------------------------------------------------------------------------------------------------
+def test_scale_estimation_masks_match_scipy_and_scale_follows_the_object_size(gpu):
+    """The Laplacian-of-Gaussian masks of the scale estimation (GPU separable filters with SciPy's derivative-of-Gaussian
+    weights, radii up to 566 taps) against scipy.ndimage.gaussian_laplace; the estimated scale grows with the size of the
+    objects and create_config works without AF_scale.  (The blob detector itself is scikit-image arithmetic in the reference:
+    restated, parity unpinned -- see superdsm_amd/automation.py.)"""
+    import scipy.ndimage as ndi
+    from superdsm_amd import automation, config
+    from superdsm_amd.globalenergymin import GlobalEnergyMinimization
+    rng = np.random.default_rng(0)
+    H, W = 300, 380
+
+    def scene(r):
+        rr, cc = np.mgrid[:H, :W]
+        im = 0.02 * rng.standard_normal((H, W))
+        for _ in range(8):
+            r0, c0 = rng.uniform(r, H - r), rng.uniform(r, W - r)
+            im += np.exp(-(((rr - r0) ** 2 + (cc - c0) ** 2) / (r * r)) ** 2)
+        return im
+
+    im = automation.normalize_image(scene(25))
+    sigmas = np.array([7.07, 14.14, 70.7, 141.4])
+    masks = automation._log_negative_masks(im, sigmas)
+    for s in sigmas:
+        ref = ndi.gaussian_laplace(im, s)
+        differ = masks[s] != (ref < 0)
+        assert differ.mean() < 1e-4 and (np.abs(ref[differ]) < 1e-12 * np.abs(ref).max()).all(), s
+    scales = [automation._estimate_scale(scene(r))[0] for r in (22, 45)]
+    assert scales[0] < scales[1] and 10 < scales[0] < 50
+    class _P:
+        stages = [GlobalEnergyMinimization()]
+    cfg, scale = automation.create_config(_P(), config.Config({}), scene(25))
+    assert abs(cfg['global-energy-minimization/beta'] - 0.66 * scale ** 2) <= 1e-9 * scale ** 2
