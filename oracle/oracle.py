@@ -87,6 +87,7 @@ def lib():
         L.orc_compute_objects.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, f64, C.POINTER(DsmCfg), i32]
         L.orc_compute_objects.restype = vp
         L.orc_set_inner_threads.argtypes = [i32]
+        L.orc_set_exact_hessian.argtypes = [i32]
         L.orc_batch_free.argtypes = [vp]
         L.orc_batch_records.argtypes = [vp]
         L.orc_batch_records.restype = vp
@@ -264,6 +265,11 @@ def compute_objects(y, y_mask, atoms, footprints, dsm_cfg, nthreads=0, inner_thr
     L.orc_batch_free(b)
     L.orc_set_inner_threads(1)
     return recs, frags, params
+
+
+def set_exact_hessian(on):
+    """Cross-check mode: Newton on the reference's exact Hessian (no row threshold, no majoriser blend)."""
+    lib().orc_set_exact_hessian(int(bool(on)))
 
 
 def max_threads():

@@ -200,3 +200,24 @@ def test_label_maps_match_reference_fixtures():
     lab2 = render.rasterize_labels(data, [a, b])
     assert set(np.unique(lab2).tolist()) == {0, 1, 2} and (lab2 > 0).sum() == 120 + 120 - 36
     assert render.rasterize_labels(data, [a], background_label=-1)[0, 0] == 65535
+
+
+def test_solver_approximations_do_not_move_the_optimum():
+    """The solver's Hessian is approximate (G~ row entries below 10 % of the row maximum dropped, regulariser curvature blended
+    towards its majoriser); psi and its gradient are exact, so the optimum must be the one plain Newton on the reference's EXACT
+    Hessian finds.  Both modes on every candidate of the 256x256 scene: same status, energies within the stated tolerance, and
+    the approximate mode needs fewer passes."""
+    from superdsm_amd import testing
+    scene = testing.make_scene('synthetic256', max_size=3)
+    args = (scene['y'], None, scene['atoms'], scene['footprints'], scene['dsm_cfg'])
+    approx, _, _ = oracle.compute_objects(*args, nthreads=8)
+    oracle.set_exact_hessian(True)
+    try:
+        exact, _, _ = oracle.compute_objects(*args, nthreads=8)
+    finally:
+        oracle.set_exact_hessian(False)
+    np.testing.assert_array_equal(approx['status'], exact['status'])
+    for k in range(len(approx)):
+        tol = 1e-6 * exact['N'][k] / 1000 + 1e-5 * abs(exact['energy'][k])
+        assert abs(approx['energy'][k] - exact['energy'][k]) <= tol, (k, approx['energy'][k], exact['energy'][k])
+    assert approx['evals'].sum() < exact['evals'].sum()
