@@ -205,6 +205,15 @@ size_t sdsm_separable_workspace_bytes(int H, int W, int R0, int R1);
 int sdsm_separable_filter(const double *d_in, int H, int W, const double *h_w0, int R0, const double *h_w1, int R1,
                           double *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- host-side combinatorial steps of the stage (no device access) -------------------------------------------------------------
+ * Approximate min-weight set cover (superdsm/minsetcover.py:4-88: greedy + merge phase, retried with beta * gamma on up to max_iter
+ * levels) and greedy max-weight set packing (superdsm/maxsetpack.py:8-24) over n objects whose footprints are bit sets of `words`
+ * uint64 each (bit = atom of the cluster); same decisions, arithmetic and tie-breaking as the reference's Python.  selected
+ * receives the indices of the solution in the reference's list order, n_selected their number. */
+int sdsm_minsetcover(int n, int words, const uint64_t *footprints, const double *energies, double beta, int merge, int max_iter,
+                     double gamma, int32_t *selected, int32_t *n_selected);
+int sdsm_maxsetpack(int n, int words, const uint64_t *footprints, const double *energies, int32_t *selected, int32_t *n_selected);
+
 /* Host helper (no device access): the foreground fragments (objects.py:148-174) of a batch out of the downloaded records and
  * bit-packed masks, one byte per pixel: fragment i (fg_h x fg_w, row-major) at out + out_offset[i]; candidates without a
  * foreground get the single byte 0 ([[False]], objects.py:172-174).  Returns the bytes written -- or needed, when out == NULL. */

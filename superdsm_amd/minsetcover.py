@@ -1,5 +1,9 @@
 """Approximate min-weight set cover on the host (reference: superdsm/minsetcover.py:4-164, Algorithm 2 of
 Kostrykin & Rohr, TPAMI 2023), restated.  Stays on the CPU by design (BASELINE.json north_star)."""
+import ctypes
+
+import numpy as np
+
 from .output import get_output
 
 DEFAULT_MAX_ITER = 5
@@ -55,15 +59,55 @@ def _solve_once(objects, beta, merge, out):
     return accepted
 
 
+def _bitsets(objects):
+    """Footprints as bit sets over the atoms that occur: (uint64 array [n, words], words)."""
+    index = {}
+    for c in objects:
+        for a in c.footprint:
+            if a not in index:
+                index[a] = len(index)
+    words = max(1, (len(index) + 63) // 64)
+    masks = np.zeros((len(objects), words), np.uint64)
+    for i, c in enumerate(objects):
+        m = 0
+        for a in c.footprint:
+            m |= 1 << index[a]
+        for w in range(words):
+            masks[i, w] = (m >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    return masks, words
+
+
 def solve_minsetcover(objects, beta, merge=True, max_iter=DEFAULT_MAX_ITER, gamma=DEFAULT_GAMMA, out=None):
     """Cover for ``beta``; retried with ``beta * gamma`` (up to ``max_iter`` levels), keeping a retry only if it is
-    cheaper when priced with the ORIGINAL beta of the level that spawned it."""
+    cheaper when priced with the ORIGINAL beta of the level that spawned it (minsetcover.py:53-88).  Runs as native host code
+    (sdsm_minsetcover, same decisions; :func:`solve_minsetcover_py` is the line-by-line restatement it is tested against)."""
+    assert beta >= 0 and 0 < gamma < 1
+    objects = list(objects)
+    if not objects:
+        return []
+    from . import _capi
+    L = _capi.lib()
+    masks, words = _bitsets(objects)
+    energies = np.ascontiguousarray([c.energy for c in objects], np.float64)
+    if not np.isfinite(energies).all():
+        return solve_minsetcover_py(objects, beta, merge, max_iter, gamma, out)
+    sel = np.zeros(len(objects), np.int32)
+    nsel = ctypes.c_int32(0)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    code = L.sdsm_minsetcover(len(objects), words, ptr(masks), ptr(energies), float(beta), int(bool(merge)), int(max_iter), float(gamma), ptr(sel), ctypes.byref(nsel))
+    assert code == 0, 'sdsm_minsetcover: bad argument'
+    get_output(out).write(f'MINSETCOVER accepted objects: {nsel.value}')
+    return [objects[i] for i in sel[:nsel.value]]
+
+
+def solve_minsetcover_py(objects, beta, merge=True, max_iter=DEFAULT_MAX_ITER, gamma=DEFAULT_GAMMA, out=None):
+    """The same in Python, statement by statement after the reference."""
     assert beta >= 0 and 0 < gamma < 1
     out = get_output(out)
     solution = _solve_once(objects, beta, merge, out)
     if max_iter > 1 and beta > 0:
         out.write(f'MINSETCOVER retry with lower beta: {beta * gamma:g}')
-        retry = solve_minsetcover(objects, beta * gamma, merge, max_iter - 1, gamma, out)
+        retry = solve_minsetcover_py(objects, beta * gamma, merge, max_iter - 1, gamma, out)
         price = lambda sol: sum(c.energy for c in sol) + beta * len(sol)
         if price(retry) < price(solution):
             return retry

@@ -204,3 +204,34 @@ def test_generations_match_reference(setcover_fixture, case, monkeypatch):
     assert len(objs) == expected['n_objects']
     assert {k: int(getattr(perf, k)) for k in perf.attributes} == expected['performance']
     assert [sorted(sorted(int(a) for a in o.footprint) for o in g) for g in gens] == [sorted(g) for g in expected['generations']]
+
+
+def test_native_set_cover_and_packing_make_the_decisions_of_the_python_restatement():
+    """sdsm_minsetcover / sdsm_maxsetpack (host C++) against the statement-by-statement Python restatements on random families:
+    overlapping footprints over up to 150 atoms (several 64-bit words), ties in the energies, every beta / merge / level count."""
+    from superdsm_amd import maxsetpack, minsetcover, objects
+    rng = np.random.default_rng(12)
+    for trial in range(60):
+        n_atoms = int(rng.integers(3, 150))
+        n = int(rng.integers(1, 60))
+        fam = []
+        for a in range(1, n_atoms + 1):                      # every atom is covered by its singleton
+            o = objects.Object()
+            o.footprint = frozenset([a])
+            o.energy = float(np.round(rng.uniform(5, 60), 1))
+            fam.append(o)
+        for _ in range(n):
+            o = objects.Object()
+            start = int(rng.integers(1, n_atoms + 1))
+            o.footprint = frozenset(range(start, min(n_atoms, start + int(rng.integers(1, 6))) + 1))
+            o.energy = float(np.round(rng.uniform(5, 200), 0))          # rounded: ties do occur
+            fam.append(o)
+        rng.shuffle(fam)
+        for beta in (0.0, 7.5, 80.0):
+            for merge in (True, False):
+                for max_iter in (1, 5):
+                    a = minsetcover.solve_minsetcover(fam, beta, merge=merge, max_iter=max_iter, out='muted')
+                    b = minsetcover.solve_minsetcover_py(fam, beta, merge=merge, max_iter=max_iter, out='muted')
+                    assert [id(o) for o in a] == [id(o) for o in b], (trial, beta, merge, max_iter)
+        a, b = maxsetpack.solve_maxsetpack(fam, out='muted'), maxsetpack.solve_maxsetpack_py(fam, out='muted')
+        assert [id(o) for o in a] == [id(o) for o in b]
