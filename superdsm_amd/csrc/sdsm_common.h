@@ -84,7 +84,7 @@ struct CandState {
     int32_t hzmax;      // largest number of 'significant' entries (>= hess_thr * row maximum) in a row of G~
     int32_t env_size;   // doubles of the solver's Hessian in envelope storage (see env_fst / env_rb)
     int32_t nneg;       // region pixels with y < 0
-    int32_t pad1;
+    int32_t yexp;       // |y| < 2^yexp for every region pixel (clamped to +-400): scale of the solver's fixed-point sums
     int32_t gcount[8];  // gcount[j] = crop positions whose row has more than 4 j entries (positions are sorted by that)
 };
 static_assert(sizeof(CandState) == 104 && SDSM_ELL_GROUPS_REG <= 8, "CandState layout");

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P)
     __shared__ unsigned long long mom[4];
     __shared__ unsigned long long scr64[SDSM_WAVES];
     __shared__ int scr32[SDSM_WAVES];
-    __shared__ int sh_M, sh_npos, sh_nneg, sh_err;
+    __shared__ int sh_M, sh_npos, sh_nneg, sh_err, sh_yhi;
     __shared__ int cls_cnt[SDSM_MAX_ELL_GROUPS + 1], cls_start[SDSM_MAX_ELL_GROUPS + 1], cls_run[SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int wave_cnt[SDSM_WAVES][SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int efirst[SDSM_MAX_N_SOLVE];             // envelope of the solver's Hessian: first coupled column per grid point
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P)
     for (int i = tid; i < (SDSM_MAX_LABELS + 1) / 32; i += SDSM_WG) fpbits[i] = 0;
     for (int i = tid; i < SDSM_MAX_BBOX_DIM / 32; i += SDSM_WG) { rowbits[i] = 0; colbits[i] = 0; }
     if (tid < 4) mom[tid] = 0;
-    if (tid == 0) { sh_M = 0; sh_npos = 0; sh_nneg = 0; sh_err = 0; }
+    if (tid == 0) { sh_M = 0; sh_npos = 0; sh_nneg = 0; sh_err = 0; sh_yhi = 0; }
     __syncthreads();
     for (int i = tid; i < cd.fp_len; i += SDSM_WG) {
         int l = P.fp_labels[cd.fp_off + i];
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P)
     const int area = cd.h * cd.w;
     int running = 0;
     unsigned long long m_r = 0, m_c = 0, m_rr = 0, m_cc = 0;
-    int npos = 0, nneg = 0;
+    int npos = 0, nneg = 0, yhi = 0;                      // yhi: high word of the largest |y| (non-negative doubles order like their bits)
     for (int base = 0; base < area; base += SDSM_WG) {
         int i = base + tid;
         bool flag = false;
@@ -245,6 +245,8 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P)
             }
             atomicOr(&rowbits[r >> 5], 1u << (r & 31));
             atomicOr(&colbits[c >> 5], 1u << (c & 31));
+            const int ah = __double2hiint(yv) & 0x7fffffff;
+            yhi = ah > yhi ? ah : yhi;
             if (yv < 0) nneg++;
             if (yv > 0) {
                 unsigned long long rr = cd.r0 + r, cc = cd.c0 + c;
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P)
         running += total;
     }
     if (nneg) atomicAdd(&sh_nneg, nneg);
+    if (yhi) atomicMax(&sh_yhi, yhi);
     if (npos) { atomicAdd(&sh_npos, npos); atomicAdd(&mom[0], m_r); atomicAdd(&mom[1], m_c); atomicAdd(&mom[2], m_rr); atomicAdd(&mom[3], m_cc); }
     __syncthreads();
 
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P)
     CandState s = {};
     s.hc = hc; s.wc = wc; s.npos = sh_npos; s.nneg = sh_nneg;
     s.sum_r = mom[0]; s.sum_c = mom[1]; s.sum_rr = mom[2]; s.sum_cc = mom[3];
+    { int ex = ((sh_yhi >> 20) & 0x7ff) - 1022; s.yexp = ex < -400 ? -400 : (ex > 400 ? 400 : ex); }
     if (running != cd.N) { s.status = ST_ERROR; if (tid == 0) *st = s; return; }          // plan / image mismatch
     if (s.npos == 1 && !P.no_trivial_rule) { s.status = ST_TRIVIAL; if (tid == 0) *st = s; return; }            // objects.py:184-191 (no solve)
 

@@ -96,6 +96,7 @@ struct Cand {                       // per-candidate global pointers (already of
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
     double reg0;                        // alpha * sqrt(epsilon) * M: the regulariser's value at xi = 0 (dsm.py:325-326)
+    int fxh_hi, fxg_hi;                 // fixed-point sums of the sparse pass (fx_add): high words of the constants 1.5 * 2^(52 + e), Hessian / gradient
 };
 
 // The evaluators are real (non-inlined) functions and receive the candidate by reference: its fields then come out of a
@@ -129,7 +130,7 @@ __device__ __forceinline__ CandState uniform_state(const CandState &d)
     CandState u;
     u.M = uni(d.M); u.status = uni(d.status); u.hc = uni(d.hc); u.wc = uni(d.wc); u.npos = uni(d.npos); u.zmax = uni(d.zmax);
     u.sum_r = uni(d.sum_r); u.sum_c = uni(d.sum_c); u.sum_rr = uni(d.sum_rr); u.sum_cc = uni(d.sum_cc);
-    u.hzmax = uni(d.hzmax); u.env_size = uni(d.env_size); u.nneg = uni(d.nneg); u.pad1 = 0;
+    u.hzmax = uni(d.hzmax); u.env_size = uni(d.env_size); u.nneg = uni(d.nneg); u.yexp = uni(d.yexp);
 #pragma unroll
     for (int j = 0; j < 8; j++) u.gcount[j] = uni(d.gcount[j]);
     return u;
@@ -145,6 +146,7 @@ __device__ __forceinline__ Cand uniform_cand(const Cand &c)
     u.p_lo = uni(c.p_lo); u.p_hi = uni(c.p_hi); u.wg = uni(c.wg); u.wG = uni(c.wG); u.wpool = (double *)uni((unsigned long long)c.wpool); u.wtimeout = uni(c.wtimeout);
     u.rmid = uni(c.rmid); u.cmid = uni(c.cmid); u.inv_hr = uni(c.inv_hr); u.inv_hc = uni(c.inv_hc);
     u.scale = uni(c.scale); u.epsilon = uni(c.epsilon); u.alpha = uni(c.alpha); u.reg0 = uni(c.reg0);
+    u.fxh_hi = uni(c.fxh_hi); u.fxg_hi = uni(c.fxg_hi);
     return u;
 }
 
@@ -618,6 +620,33 @@ __device__ __forceinline__ double eval_full_ell(const Cand &c PROF_PARAM)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Fixed-point accumulation of the sparse pass.  The per-pixel products go to the Hessian / gradient entries through LDS
+// atomics, and an integer add (ds_add_u64, 12 clocks per wavefront instruction on scattered addresses) costs half of a
+// floating-point one (ds_add_f64: 21; tools/microbench/lds_rates.hip) -- and integer sums do not depend on the order of
+// the additions, so a launch reproduces its results bit for bit.  A product a * b becomes an integer multiple of the unit
+// 2^e by ONE instruction: fma(a, b, C) with C = 1.5 * 2^(52 + e) rounds a * b to a multiple of 2^e and leaves it, offset by
+// the bits of C, in the mantissa (valid for |a b| < 2^(51 + e)).  e is chosen per candidate from the bound on a term (|y| <
+// 2^yexp from the setup kernel, weights <= 1, |u|, |v| <= 1) and the number of pixels, so that a term has up to 50 bits and
+// the sum of all terms stays below 2^62: for N <= 2048 pixels the resolution of a term is that of a double.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fx_exponents(int yexp, int N, int *hh, int *gh)
+{
+    const int lg = N > 1 ? 32 - __builtin_clz((unsigned)(N - 1)) : 0;       // ceil(log2 N)
+    const int bits = 61 - lg < 50 ? 61 - lg : 50;
+    const int eh = 2 * yexp - 1 - bits, eg = yexp - bits;                   // Hessian terms < 2^(2 yexp - 1), gradient terms < 2^yexp
+    *hh = ((1075 + eh) << 20) | 0x80000;
+    *gh = ((1075 + eg) << 20) | 0x80000;
+}
+__device__ __forceinline__ void fx_add(double *addr, double a, double b, int chi)
+{
+    const double s = fma(a, b, __hiloint2double(chi, 0));
+    const unsigned long long v = ((unsigned long long)(unsigned)(__double2hiint(s) - chi) << 32) | (unsigned)__double2loint(s);
+    atomicAdd(reinterpret_cast<unsigned long long *>(addr), v);
+}
+__device__ __forceinline__ double fx_unit(int chi) { return __hiloint2double((chi & 0x7ff00000) - (52 << 20), 0); }
+__device__ __forceinline__ double fx_get(double raw, double unit) { return (double)__double_as_longlong(raw) * unit; }
+
+// ---------------------------------------------------------------------------------------------------------
 // SPARSE full evaluation (n > 40): per-pixel products added into the packed Hessian in LDS (ds_add_f64).
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
@@ -673,7 +702,7 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
                     if (q0 < c.gcount[j]) {
 #pragma unroll
                         for (int k = 0; k < 4; k++)
-                            if (4 * j + k < nnz) atomicAdd(&g[6 + RID(ip, 4 * j + k)], r * (double)w[4 * j + k]);   // exact gradient: every entry
+                            if (4 * j + k < nnz) fx_add(&g[6 + RID(ip, 4 * j + k)], r, (double)w[4 * j + k], c.fxg_hi);   // exact gradient: every entry
                     }
                 }
                 FINE_ADD(11);
@@ -687,19 +716,19 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
                             const double dwa = dc * (double)w[a];
                             const int ia = RID(ip, a);
 #pragma unroll
-                            for (int b = 0; b < 6; b++) atomicAdd(&Hp[rbt[b] + ia], dwa * q[b]);      // theta rows, column xi_ia
+                            for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);      // theta rows, column xi_ia
 #pragma unroll
-                            for (int b = 0; b <= a; b++) atomicAdd(&Hp[rbs[a] + RID(ip, b)], dwa * (double)w[b]);   // leading entries are in ascending column order
+                            for (int b = 0; b <= a; b++) fx_add(&Hp[rbs[a] + RID(ip, b)], dwa, (double)w[b], c.fxh_hi);   // leading entries are in ascending column order
                         }
                     }
                 } else {
                     for (int a = 0; a < hnz; a++) {
                         const double dwa = dc * (double)ell_w_at(c, a, p);
                         const int ia = ell_i_at(c, a, p);
-                        for (int b = 0; b < 6; b++) atomicAdd(&Hp[rbt[b] + ia], dwa * q[b]);
+                        for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);
                         for (int b = 0; b <= a; b++) {
                             const int ib = ell_i_at(c, b, p);
-                            atomicAdd(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa * (double)ell_w_at(c, b, p));
+                            fx_add(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa, (double)ell_w_at(c, b, p), c.fxh_hi);
                         }
                     }
                 }
@@ -707,12 +736,12 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
                 for (int a = 0; a < nnz; a++) {
                     const double wa = (double)ell_w_at(c, a, p), dwa = dc * wa;
                     const int ia = ell_i_at(c, a, p);
-                    atomicAdd(&g[6 + ia], r * wa);
+                    fx_add(&g[6 + ia], r, wa, c.fxg_hi);
                     if (a >= hnz) continue;
-                    for (int b = 0; b < 6; b++) atomicAdd(&Hp[rbt[b] + ia], dwa * q[b]);
+                    for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);
                     for (int b = 0; b <= a; b++) {
                         const int ib = ell_i_at(c, b, p);
-                        atomicAdd(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa * (double)ell_w_at(c, b, p));
+                        fx_add(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa, (double)ell_w_at(c, b, p), c.fxh_hi);
                     }
                 }
             }
@@ -721,7 +750,13 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
     }
     PROF_ADD(0, pt);
     double *tot = SD + L::TMP;                           // TMP is free outside factor_solve
-    moments_total<L>(red, tot);
+    moments_total<L>(red, tot);                          // (its barriers: every atomic of the pass has landed)
+    {
+        const double uh = fx_unit(c.fxh_hi), ug = fx_unit(c.fxg_hi);
+        for (int e = tid; e < c.env_size; e += L::WGS) Hp[e] = fx_get(Hp[e], uh);
+        for (int i = 6 + tid; i < n; i += L::WGS) g[i] = fx_get(g[i], ug);
+    }
+    __syncthreads();
     if (tid < 6) g[tid] = moment_grad(tot, tid);
     if (tid < 21) {
         int a = 0;
@@ -1243,6 +1278,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
     c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * Mfull;   // (only read by passes with M = Mfull > 0)
+    fx_exponents(st.yexp, cd.N, &c.fxh_hi, &c.fxg_hi);
     // local frame: centre of the bounding box, half extents
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
@@ -1466,6 +1502,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = M > 0 ? st.gcount[j] : 0;
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N; c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * M;
+    fx_exponents(st.yexp, cd.N, &c.fxh_hi, &c.fxg_hi);
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
     c.inv_hr = 1.0 / (half_r < 1 ? 1 : half_r); c.inv_hc = 1.0 / (half_c < 1 ? 1 : half_c);

@@ -25,6 +25,9 @@ template <int MODE, int WG> __global__ __launch_bounds__(WG) void k(double *out,
             else if (MODE == 4) atomicAdd(&buf[(threadIdx.x + u * 64 + it) & (spread - 1)], 1.0);   // conflict-free f64 atomics
             else if (MODE == 5) { acc += (double)a; }                         // index generation only
             else if (MODE == 6) buf[a] = acc;                            // ds_write_b64 scattered
+            else if (MODE == 7) atomicAdd(reinterpret_cast<unsigned long long *>(buf) + a, (unsigned long long)s);   // ds_add_u64
+            else if (MODE == 8) atomicAdd(reinterpret_cast<unsigned *>(buf) + a, s);                                  // ds_add_u32
+            else if (MODE == 9) { atomicAdd(&buf[a], 1.0); atomicAdd(&buf[a ^ 1], 1.0); }                             // pairs of neighbours
         }
     }
     __syncthreads();
@@ -56,6 +59,9 @@ int main()
         run<2, 256>("ds_read_b64 scattered", 256, spread);
         run<3, 256>("ds_read_b32 scattered", 256, spread);
         run<6, 256>("ds_write_b64 scattered", 256, spread);
+        run<7, 256>("ds_add_u64 scattered", 256, spread);
+        run<8, 256>("ds_add_u32 scattered", 256, spread);
+        run<9, 256>("2x ds_add_f64 neighbours", 256, spread);
     }
     run<4, 256>("ds_add_f64 conflict-free", 256, 4096);
     run<5, 256>("index generation only", 256, 4096);
