@@ -779,6 +779,66 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
     return uni(psi);
 }
 
+// Back substitution L^T z = yrow by ONE wavefront (n <= 64 KY).  The right-hand side lives in its registers (row i: lane i & 63,
+// register i >> 6) together with the row bases, first columns and reciprocal pivots of those rows; column j of L^T is row j of
+// the factor -- one contiguous read whose address does not depend on the solution, requested BS_DEPTH - 1 steps ahead.  A step
+// is then: scale y_j, broadcast it (v_readlane), one multiply-add per register: no barrier and no memory round trip on the
+// dependent chain (the blocked version with one workgroup barrier per panel took 18 us for n = 50, 44 % of factor_solve).
+template <int KY>
+__device__ __forceinline__ void back_substitute_wave(const double *Hp, const double *yrow, const double *dg, const int *rbp, const int *fstp, double *zl, int n, int tid)
+{
+    constexpr int BS_DEPTH = 4;
+    if (tid < 64) {
+        double yv[KY], dgv[KY];
+        int rbv[KY], fsv[KY];
+#pragma unroll
+        for (int k = 0; k < KY; k++) {
+            const int i = tid + 64 * k;
+            const bool in = i < n;
+            yv[k] = in ? yrow[i] : 0.0; dgv[k] = in ? dg[i] : 0.0; rbv[k] = in ? rbp[i] : 0; fsv[k] = in ? fstp[i] : 0;
+        }
+        double buf[BS_DEPTH][KY];
+        auto fetch = [&](int j, double (&r)[KY]) {           // row j of the factor, columns fst[j] .. j - 1 (0 elsewhere)
+            const int kj = j >> 6, lj = j & 63;
+            int rbs = 0, fss = 0;
+#pragma unroll
+            for (int k = 0; k < KY; k++) { rbs = k == kj ? rbv[k] : rbs; fss = k == kj ? fsv[k] : fss; }
+            const int rb = __builtin_amdgcn_readlane(rbs, lj), f = __builtin_amdgcn_readlane(fss, lj);
+#pragma unroll
+            for (int k = 0; k < KY; k++) {
+                const int i = tid + 64 * k;
+                r[k] = 0.0;
+                if (k <= kj) { if (i >= f && i < j) r[k] = Hp[rb + i]; }
+            }
+        };
+#pragma unroll
+        for (int s2 = 0; s2 < BS_DEPTH - 1; s2++) if (n - 1 - s2 >= 0) fetch(n - 1 - s2, buf[s2]);
+        for (int jb = n - 1; jb >= 0; jb -= BS_DEPTH) {
+#pragma unroll
+            for (int s2 = 0; s2 < BS_DEPTH; s2++) {
+                const int j = jb - s2;
+                if (j >= 0) {
+                    if (j - (BS_DEPTH - 1) >= 0) fetch(j - (BS_DEPTH - 1), buf[(s2 + BS_DEPTH - 1) % BS_DEPTH]);
+                    const int kj = j >> 6, lj = j & 63;
+                    double zc = 0;
+#pragma unroll
+                    for (int k = 0; k < KY; k++) zc = k == kj ? yv[k] * dgv[k] : zc;
+                    const double zj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zc), lj), __builtin_amdgcn_readlane(__double2loint(zc), lj));
+#pragma unroll
+                    for (int k = 0; k < KY; k++) {
+                        if (k <= kj) {
+                            const int i = tid + 64 * k;
+                            yv[k] = i == j ? zj : fma(-buf[s2][k], zj, yv[k]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KY; k++) { const int i = tid + 64 * k; if (i < n) zl[i] = yv[k]; }
+    }
+}
+
 // 1 / sqrt(x), x in the normal range: hardware estimate (5.2e-8 relative) + ONE Newton step = 4.2e-15 relative (37 ulp,
 // tools/microbench/rsq_accuracy.hip).  The pivots of the Cholesky factorisation sit on its dependent chain, and a factor of
 // an approximate Hessian does not need the last bits.
@@ -1012,37 +1072,45 @@ __device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in,
     double l2 = 0;
     for (int i = tid; i < n; i += L::WGS) l2 += yrow[i] * yrow[i];
     l2 = block_sum<L::NWAVES>(l2, SD + L::RED);
-    // back substitution L^T z = yrow, blocked the same way: the threads that have a row to update (or write the block's
-    // solution) solve the NB x NB block redundantly
-    for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
-        const int nb = n - j0 < NB ? n - j0 : NB;
-        int f4[NB];
-#pragma unroll
-        for (int cc = 0; cc < NB; cc++) f4[cc] = cc < nb ? uni(fstp[j0 + cc]) : j0;
-        const int start = j0 + nb - 1 >= M ? 0 : f4[0];          // fst is non-decreasing over the xi rows, 0 for theta rows
-        if (tid < NB || start + tid < j0) {
-            double z[NB];
-#pragma unroll
-            for (int cc = NB - 1; cc >= 0; cc--) {
-                double acc = cc < nb ? yrow[j0 + cc] : 0.0;
-#pragma unroll
-                for (int m = cc + 1; m < NB; m++) if (m < nb) acc -= Hp[rbp[j0 + m] + j0 + cc] * z[m];
-                z[cc] = cc < nb ? acc * dg[j0 + cc] : 0.0;
-            }
-            if (tid < NB && tid < nb) {
-                double v = 0;
-#pragma unroll
-                for (int x2 = 0; x2 < NB; x2++) v = x2 == tid ? z[x2] : v;
-                zl[j0 + tid] = v;
-            }
-            for (int i = start + tid; i < j0; i += L::WGS) {
-                double acc = yrow[i];
-#pragma unroll
-                for (int cc = 0; cc < NB; cc++) if (cc < nb && i >= f4[cc]) acc -= Hp[rbp[j0 + cc] + i] * z[cc];
-                yrow[i] = acc;
-            }
-        }
+    // back substitution L^T z = yrow: by one wavefront in registers when n <= 256 (back_substitute_wave), else blocked like the
+    // factorisation (one barrier per panel)
+    if (L::NMAX <= 128 || n <= 256) {
+        if constexpr (L::NMAX <= 128) back_substitute_wave<2>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
+        else back_substitute_wave<4>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
         __syncthreads();
+    } else {
+        // back substitution L^T z = yrow, blocked the same way: the threads that have a row to update (or write the block's
+        // solution) solve the NB x NB block redundantly
+        for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
+            const int nb = n - j0 < NB ? n - j0 : NB;
+            int f4[NB];
+    #pragma unroll
+            for (int cc = 0; cc < NB; cc++) f4[cc] = cc < nb ? uni(fstp[j0 + cc]) : j0;
+            const int start = j0 + nb - 1 >= M ? 0 : f4[0];          // fst is non-decreasing over the xi rows, 0 for theta rows
+            if (tid < NB || start + tid < j0) {
+                double z[NB];
+    #pragma unroll
+                for (int cc = NB - 1; cc >= 0; cc--) {
+                    double acc = cc < nb ? yrow[j0 + cc] : 0.0;
+    #pragma unroll
+                    for (int m = cc + 1; m < NB; m++) if (m < nb) acc -= Hp[rbp[j0 + m] + j0 + cc] * z[m];
+                    z[cc] = cc < nb ? acc * dg[j0 + cc] : 0.0;
+                }
+                if (tid < NB && tid < nb) {
+                    double v = 0;
+    #pragma unroll
+                    for (int x2 = 0; x2 < NB; x2++) v = x2 == tid ? z[x2] : v;
+                    zl[j0 + tid] = v;
+                }
+                for (int i = start + tid; i < j0; i += L::WGS) {
+                    double acc = yrow[i];
+    #pragma unroll
+                    for (int cc = 0; cc < NB; cc++) if (cc < nb && i >= f4[cc]) acc -= Hp[rbp[j0 + cc] + i] * z[cc];
+                    yrow[i] = acc;
+                }
+            }
+            __syncthreads();
+        }
     }
     bool fin = isfinite(l2);
     for (int i = tid; i < n; i += L::WGS) {
