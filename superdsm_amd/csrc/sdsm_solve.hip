@@ -83,6 +83,7 @@ struct Lay {
 struct Cand {                       // per-candidate global pointers (already offset) and scalars
     g_cdouble_p crop_y;
     g_cu32_p crop_rc;
+    g_double_p pix_r, pix_d;            // per-pixel loss derivative / curvature between the loops of the sparse pass
     g_cf32x4_p ell_w4;                  // group j of position p: element j * N + p (4 weights)
     g_cu16x4_p ell_i4;                  // (4 column indices)
     g_cu32_p ell_meta;                  // row entries | Hessian entries << 16
@@ -138,7 +139,7 @@ __device__ __forceinline__ CandState uniform_state(const CandState &d)
 __device__ __forceinline__ Cand uniform_cand(const Cand &c)
 {
     Cand u;
-    u.crop_y = uni(c.crop_y); u.crop_rc = uni(c.crop_rc); u.ell_w4 = uni(c.ell_w4); u.ell_i4 = uni(c.ell_i4); u.ell_meta = uni(c.ell_meta);
+    u.crop_y = uni(c.crop_y); u.crop_rc = uni(c.crop_rc); u.pix_r = uni(c.pix_r); u.pix_d = uni(c.pix_d); u.ell_w4 = uni(c.ell_w4); u.ell_i4 = uni(c.ell_i4); u.ell_meta = uni(c.ell_meta);
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) u.gcount[j] = uni(c.gcount[j]);
     u.hglob = (double *)uni((unsigned long long)c.hglob);
@@ -658,73 +659,110 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
     double *Hp = hess_ptr<L>(c), *g = SD + L::G;
     const double *xv = SD + L::X;
     const int *rbp = RBP;
+    double *tot = SD + L::TMP;                           // TMP is free outside factor_solve
     for (int e = tid; e < c.env_size; e += L::WGS) Hp[e] = 0;
     for (int i = tid; i < n; i += L::WGS) g[i] = 0;
-    int rbt[6];                                          // the 6 dense theta rows (uniform)
-#pragma unroll
-    for (int b = 0; b < 6; b++) rbt[b] = __builtin_amdgcn_readfirstlane(rbp[M + b]);
     __syncthreads();
-    double red[NMOM];                                    // psi and the coordinate moments of r and d (add_moments)
-#pragma unroll
-    for (int k = 0; k < NMOM; k++) red[k] = 0;
     const int zm = M > 0 ? c.zmax : 0;
     const bool in_regs = zm <= ZREG;
-    for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
-        FINE_START();
-        double yv = c.crop_y[p];
-        uint32_t rc = c.crop_rc[p];
-        double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-        double q[6] = {u * u, v * v, 2 * (u * v), 2 * u, 2 * v, 1.0};
-        double Sv = q[0] * xv[0] + q[1] * xv[1] + q[2] * xv[2] + q[3] * xv[3] + q[4] * xv[4] + xv[5];
-        const uint32_t meta = M > 0 ? c.ell_meta[p] : 0u;
-        const int nnz = (int)(meta & 0xffffu);
-        float w[ZREG]; RowIds ip;
-        if (in_regs) {
-            load_row(c, p, w, ip);
+    // Two loops over the pixels, each with a small set of live registers (the kernel runs three wavefronts per SIMD):
+    // A: S, the loss terms, psi and the polynomial gradient sums; the derivative r and curvature d of every pixel are parked in
+    //    global memory (read back by the same thread: no synchronisation);
+    // B: the atomics -- gradient entries of xi (all row entries), Hessian entries (leading row entries) -- and the polynomial
+    //    Hessian sums.
+    {
+        double ra[7];                                    // add_moments' m[0 .. 6]
+#pragma unroll
+        for (int k = 0; k < 7; k++) ra[k] = 0;
+        for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
+            FINE_START();
+            const double yv = c.crop_y[p];
+            const uint32_t rc = c.crop_rc[p];
+            const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
+            double Sv = (u * u) * xv[0] + (v * v) * xv[1] + (2 * (u * v)) * xv[2] + (2 * u) * xv[3] + (2 * v) * xv[4] + xv[5];
             FINE_ADD(8);
-            Sv += gather_row(c, xv, p, w, ip);
-        } else if (M > 0) Sv += smooth_term(c, xv, p);
-        FINE_ADD(9);
-        double phi, r, dc;
-        loss_terms(yv, Sv, &phi, &r, &dc);
-        add_moments(red, phi, r, dc, u, v);
-        FINE_ADD(10);
-        if (dc != 0 || r != 0) {
-            const int hnz = (int)(meta >> 16);
-            if (in_regs) {
-                const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
-                // the weights are converted to double again here (and below): keeping the 28 converted values of the
-                // gather alive across the loss costs 56 registers, a conversion costs one instruction
+            if (M > 0) Sv += smooth_term(c, xv, p);
+            FINE_ADD(9);
+            double phi, r, dc;
+            loss_terms(yv, Sv, &phi, &r, &dc);
+            ra[0] += phi;
+            ra[1] += r; ra[2] += r * u; ra[3] += r * v; ra[4] += r * (u * u); ra[5] += r * (u * v); ra[6] += r * (v * v);
+            c.pix_r[p] = r; c.pix_d[p] = dc;
+            FINE_ADD(10);
+        }
+        block_sum_scatter<7, L::NWAVES>(ra, SD + L::RED);
+        if (tid < 7) tot[tid] = sum_scatter_total<7, L::NWAVES>(SD + L::RED, tid);
+    }
+    PROF_ADD(0, pt);
+    {
+        int rbt[6];                                      // the 6 dense theta rows (uniform)
 #pragma unroll
-                for (int s2 = 0; s2 < ZREG; s2++) asm volatile("" : "+v"(w[s2]));
+        for (int b = 0; b < 6; b++) rbt[b] = __builtin_amdgcn_readfirstlane(rbp[M + b]);
+        double rh[15];                                   // add_moments' m[7 .. 21]
 #pragma unroll
-                for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
-                    if (q0 < c.gcount[j]) {
+        for (int k = 0; k < 15; k++) rh[k] = 0;
+        for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
+            FINE_START();
+            const double dc = c.pix_d[p], r = c.pix_r[p];
+            const uint32_t rc = c.crop_rc[p];
+            const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
+            {
+                const double uu = u * u, uv = u * v, vv = v * v;
+                const double duu = dc * uu, duv = dc * uv, dvv = dc * vv;
+                rh[0] += dc; rh[1] += dc * u; rh[2] += dc * v; rh[3] += duu; rh[4] += duv; rh[5] += dvv;
+                rh[6] += duu * u; rh[7] += duu * v; rh[8] += dvv * u; rh[9] += dvv * v;
+                rh[10] += duu * uu; rh[11] += duu * uv; rh[12] += duu * vv; rh[13] += dvv * uv; rh[14] += dvv * vv;
+            }
+            if (dc != 0 || r != 0) {
+                const double q[6] = {u * u, v * v, 2 * (u * v), 2 * u, 2 * v, 1.0};
+                const uint32_t meta = c.ell_meta[p];
+                const int nnz = (int)(meta & 0xffffu), hnz = (int)(meta >> 16);
+                if (in_regs) {
+                    float w[ZREG]; RowIds ip;
+                    load_row(c, p, w, ip);
+                    FINE_ADD(8);
+                    const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if (4 * j + k < nnz) fx_add(&g[6 + RID(ip, 4 * j + k)], r, (double)w[4 * j + k], c.fxg_hi);   // exact gradient: every entry
+                    for (int j = SDSM_ELL_GROUPS_REG - 1; j >= 0; j--) {          // (the leading entries, groups 0 .. 2, are used again below)
+                        if (q0 < c.gcount[j]) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (4 * j + k < nnz) fx_add(&g[6 + RID(ip, 4 * j + k)], r, (double)w[4 * j + k], c.fxg_hi);   // exact gradient: every entry
+                        }
                     }
-                }
-                FINE_ADD(11);
-                if (c.hzmax <= HZREG) {
-                    int rbs[HZREG];                                                      // row bases of the leading entries
+                    FINE_ADD(11);
+                    if (c.hzmax <= HZREG) {
+                        int rbs[HZREG];                                                      // row bases of the leading entries
 #pragma unroll
-                    for (int a = 0; a < HZREG; a++) rbs[a] = a < hnz ? rbp[RID(ip, a)] : 0;
+                        for (int a = 0; a < HZREG; a++) rbs[a] = a < hnz ? rbp[RID(ip, a)] : 0;
 #pragma unroll
-                    for (int a = 0; a < HZREG; a++) {                                    // approximate Hessian: leading entries
-                        if (a < hnz) {
-                            const double dwa = dc * (double)w[a];
-                            const int ia = RID(ip, a);
+                        for (int a = 0; a < HZREG; a++) {                                    // approximate Hessian: leading entries
+                            if (a < hnz) {
+                                const double dwa = dc * (double)w[a];
+                                const int ia = RID(ip, a);
 #pragma unroll
-                            for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);      // theta rows, column xi_ia
+                                for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);      // theta rows, column xi_ia
 #pragma unroll
-                            for (int b = 0; b <= a; b++) fx_add(&Hp[rbs[a] + RID(ip, b)], dwa, (double)w[b], c.fxh_hi);   // leading entries are in ascending column order
+                                for (int b = 0; b <= a; b++) fx_add(&Hp[rbs[a] + RID(ip, b)], dwa, (double)w[b], c.fxh_hi);   // leading entries are in ascending column order
+                            }
+                        }
+                    } else {
+                        for (int a = 0; a < hnz; a++) {
+                            const double dwa = dc * (double)ell_w_at(c, a, p);
+                            const int ia = ell_i_at(c, a, p);
+                            for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);
+                            for (int b = 0; b <= a; b++) {
+                                const int ib = ell_i_at(c, b, p);
+                                fx_add(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa, (double)ell_w_at(c, b, p), c.fxh_hi);
+                            }
                         }
                     }
                 } else {
-                    for (int a = 0; a < hnz; a++) {
-                        const double dwa = dc * (double)ell_w_at(c, a, p);
+                    for (int a = 0; a < nnz; a++) {
+                        const double wa = (double)ell_w_at(c, a, p), dwa = dc * wa;
                         const int ia = ell_i_at(c, a, p);
+                        fx_add(&g[6 + ia], r, wa, c.fxg_hi);
+                        if (a >= hnz) continue;
                         for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);
                         for (int b = 0; b <= a; b++) {
                             const int ib = ell_i_at(c, b, p);
@@ -732,25 +770,12 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
                         }
                     }
                 }
-            } else {
-                for (int a = 0; a < nnz; a++) {
-                    const double wa = (double)ell_w_at(c, a, p), dwa = dc * wa;
-                    const int ia = ell_i_at(c, a, p);
-                    fx_add(&g[6 + ia], r, wa, c.fxg_hi);
-                    if (a >= hnz) continue;
-                    for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);
-                    for (int b = 0; b <= a; b++) {
-                        const int ib = ell_i_at(c, b, p);
-                        fx_add(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa, (double)ell_w_at(c, b, p), c.fxh_hi);
-                    }
-                }
             }
+            FINE_ADD(12);
         }
-        FINE_ADD(12);
+        block_sum_scatter<15, L::NWAVES>(rh, SD + L::RED);            // (its barriers: every atomic of the pass has landed)
+        if (tid < 15) tot[7 + tid] = sum_scatter_total<15, L::NWAVES>(SD + L::RED, tid);
     }
-    PROF_ADD(0, pt);
-    double *tot = SD + L::TMP;                           // TMP is free outside factor_solve
-    moments_total<L>(red, tot);                          // (its barriers: every atomic of the pass has landed)
     {
         const double uh = fx_unit(c.fxh_hi), ug = fx_unit(c.fxg_hi);
         for (int e = tid; e < c.env_size; e += L::WGS) Hp[e] = fx_get(Hp[e], uh);
@@ -1340,6 +1365,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         for (int i = tid; i < (cd.h * cd.w + 31) / 32; i += L::WGS) mk0[i] = 0;
     }
     c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
+    c.pix_r = (g_double_p)(P.tmp_y + cd.crop_off); c.pix_d = (g_double_p)(P.pix_d + cd.crop_off);
     c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = Mfull > 0 ? st.gcount[j] : 0;
@@ -1565,6 +1591,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     c.N = cd.N; c.zmax = M > 0 ? st.zmax : 0; c.hzmax = M > 0 ? st.hzmax : 0; c.env_size = efull;
     c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr; c.wtimeout = 0;
     c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
+    c.pix_r = (g_double_p)(P.tmp_y + cd.crop_off); c.pix_d = (g_double_p)(P.pix_d + cd.crop_off);
     c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = M > 0 ? st.gcount[j] : 0;
@@ -1708,7 +1735,12 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
         if (n_d > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, INT_MAX, INT_MAX, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
     }
-    if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 2>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
+    // class 1 at THREE wavefronts per SIMD (168 registers; measured 6.54 vs 7.43 ms at two: the solver is latency bound and a third
+    // workgroup per compute unit fills its stalls, at the price of ~35 spilled registers; four -- 128 registers -- spill 73: 10.9 ms)
+    // class 1 runs THREE wavefronts per SIMD (168 registers, no scratch: the sparse pass is split into two lean loops for that).
+    // Measured on the 8-image launch: 8.10 ms at two, 6.33 ms at three, 6.57 ms at four (128 registers: 36 spilled, in the
+    // line-search and atomics loops) -- the solver is latency bound and a third workgroup per compute unit fills its stalls.
+    if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
     if ((n_c > 0 || n_d > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
     if (n_w > 0 && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
