@@ -814,49 +814,53 @@ __device__ __forceinline__ void back_substitute_wave(const double *Hp, const dou
 {
     constexpr int BS_DEPTH = 4;
     if (tid < 64) {
+        // scaled unknowns: with y~_i = y_i / l_ii the solution is z_j = y~_j once the columns j' > j are eliminated, and
+        // eliminating column j is y~_i -= (l_ji / l_ii) z_j: the factor's row is scaled before z_j is known (off the dependent
+        // chain), a step is two v_readlane and one multiply-add per register
         double yv[KY], dgv[KY];
         int rbv[KY], fsv[KY];
 #pragma unroll
         for (int k = 0; k < KY; k++) {
             const int i = tid + 64 * k;
             const bool in = i < n;
-            yv[k] = in ? yrow[i] : 0.0; dgv[k] = in ? dg[i] : 0.0; rbv[k] = in ? rbp[i] : 0; fsv[k] = in ? fstp[i] : 0;
+            dgv[k] = in ? dg[i] : 0.0; yv[k] = in ? yrow[i] * dgv[k] : 0.0; rbv[k] = in ? rbp[i] : 0; fsv[k] = in ? fstp[i] : 0;
         }
-        double buf[BS_DEPTH][KY];
-        auto fetch = [&](int j, double (&r)[KY]) {           // row j of the factor, columns fst[j] .. j - 1 (0 elsewhere)
+        double buf[BS_DEPTH][KY], msk[BS_DEPTH][KY];          // raw row entries; the lane's reciprocal pivot where the row has an entry, else 0
+        auto fetch = [&](int j, double (&r)[KY], double (&m)[KY]) {           // row j of the factor, columns fst[j] .. j - 1 (0 elsewhere)
             const int kj = j >> 6, lj = j & 63;
-            int rbs = 0, fss = 0;
+            int rbs = rbv[0], fss = fsv[0];
 #pragma unroll
-            for (int k = 0; k < KY; k++) { rbs = k == kj ? rbv[k] : rbs; fss = k == kj ? fsv[k] : fss; }
+            for (int k = 1; k < KY; k++) { rbs = k == kj ? rbv[k] : rbs; fss = k == kj ? fsv[k] : fss; }
             const int rb = __builtin_amdgcn_readlane(rbs, lj), f = __builtin_amdgcn_readlane(fss, lj);
 #pragma unroll
             for (int k = 0; k < KY; k++) {
                 const int i = tid + 64 * k;
-                r[k] = 0.0;
-                if (k <= kj) { if (i >= f && i < j) r[k] = Hp[rb + i]; }
+                const bool in = i >= f && i < j;             // (no branch around the load: every lane reads, entry (j, j) if it has none)
+                r[k] = Hp[rb + (in ? i : j)];                // used BS_DEPTH - 1 steps later: nothing here waits for it
+                m[k] = in ? dgv[k] : 0.0;
             }
         };
+        // No branch inside the loop (the compiler's wait counts for the rows in flight are exact only in straight-line code): the
+        // steps start at the next multiple of BS_DEPTH above n -- rows >= n have y~ = 0, so whatever is fetched for them is
+        // multiplied by zero -- and the rows requested beyond row 0 at the end are row 0 again.
+        const int jtop = ((n + BS_DEPTH - 1) / BS_DEPTH) * BS_DEPTH - 1;
 #pragma unroll
-        for (int s2 = 0; s2 < BS_DEPTH - 1; s2++) if (n - 1 - s2 >= 0) fetch(n - 1 - s2, buf[s2]);
-        for (int jb = n - 1; jb >= 0; jb -= BS_DEPTH) {
+        for (int s2 = 0; s2 < BS_DEPTH - 1; s2++) fetch(jtop - s2, buf[s2], msk[s2]);
+        for (int jb = jtop; jb >= 0; jb -= BS_DEPTH) {
 #pragma unroll
             for (int s2 = 0; s2 < BS_DEPTH; s2++) {
-                const int j = jb - s2;
-                if (j >= 0) {
-                    if (j - (BS_DEPTH - 1) >= 0) fetch(j - (BS_DEPTH - 1), buf[(s2 + BS_DEPTH - 1) % BS_DEPTH]);
-                    const int kj = j >> 6, lj = j & 63;
-                    double zc = 0;
+                const int j = jb - s2, jf = j - (BS_DEPTH - 1);
+                fetch(jf > 0 ? jf : 0, buf[(s2 + BS_DEPTH - 1) % BS_DEPTH], msk[(s2 + BS_DEPTH - 1) % BS_DEPTH]);
+                const int kj = j >> 6, lj = j & 63;
+                double sc[KY];                               // the row scaled by the lanes' reciprocal pivots: before the broadcast, off the chain
 #pragma unroll
-                    for (int k = 0; k < KY; k++) zc = k == kj ? yv[k] * dgv[k] : zc;
-                    const double zj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zc), lj), __builtin_amdgcn_readlane(__double2loint(zc), lj));
+                for (int k = 0; k < KY; k++) sc[k] = buf[s2][k] * msk[s2][k];
+                double zc = yv[0];
 #pragma unroll
-                    for (int k = 0; k < KY; k++) {
-                        if (k <= kj) {
-                            const int i = tid + 64 * k;
-                            yv[k] = i == j ? zj : fma(-buf[s2][k], zj, yv[k]);
-                        }
-                    }
-                }
+                for (int k = 1; k < KY; k++) zc = k == kj ? yv[k] : zc;
+                const double zj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zc), lj), __builtin_amdgcn_readlane(__double2loint(zc), lj));
+#pragma unroll
+                for (int k = 0; k < KY; k++) yv[k] = fma(-sc[k], zj, yv[k]);    // rows >= j have a zero there: they keep their solution
             }
         }
 #pragma unroll
@@ -1100,7 +1104,8 @@ __device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in,
     // back substitution L^T z = yrow: by one wavefront in registers when n <= 256 (back_substitute_wave), else blocked like the
     // factorisation (one barrier per panel)
     if (L::NMAX <= 128 || n <= 256) {
-        if constexpr (L::NMAX <= 128) back_substitute_wave<2>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
+        if (n <= 64) back_substitute_wave<1>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
+        else if constexpr (L::NMAX <= 128) back_substitute_wave<2>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
         else back_substitute_wave<4>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
         __syncthreads();
     } else {
