@@ -122,6 +122,19 @@ __device__ __forceinline__ void rows_of_ranks(const BatchParams &P, const CandDe
         // column order, so the solve kernel knows which of a pair is the row --, the others from slot nnz - 1 downwards
         const float lim = P.hess_thr * __fdiv_rn(c.wmax, sum);
         int hz = 0, others = 0, mn = 0;
+        // The entries leave as whole 4-entry groups (one 16-byte store of weights + one 8-byte store of column indices, what the
+        // solve kernel loads), not as 2- and 4-byte stores scattered over the groups: the leading entries fill a register buffer
+        // upwards from slot 0, the others a second one downwards from slot nnz - 1; a buffer is stored when its group is complete,
+        // the group in which the two meet at the end.
+        float fw[4] = {0.f, 0.f, 0.f, 0.f}, bw[4] = {0.f, 0.f, 0.f, 0.f};
+        int fi[4] = {0, 0, 0, 0}, bi[4] = {0, 0, 0, 0};
+        auto store_group = [&](int g, const float (&w4)[4], const int (&i4)[4]) {
+            const int64_t e = ell_at(base, cd.N, 4 * g);
+            f32x4 wv; wv.x = w4[0]; wv.y = w4[1]; wv.z = w4[2]; wv.w = w4[3];
+            *reinterpret_cast<f32x4 *>(P.ell_w + e) = wv;
+            uint2 iv; iv.x = (uint32_t)i4[0] | ((uint32_t)i4[1] << 16); iv.y = (uint32_t)i4[2] | ((uint32_t)i4[3] << 16);
+            *reinterpret_cast<uint2 *>(P.ell_idx + e) = iv;
+        };
         for (int j = c.jlo; j < c.jhi; j++) {
             const uint32_t gk = gridkeys[j];
             int dr = (int)(gk >> 16) - c.cr, dc = (int)(gk & 0xffffu) - c.cc;
@@ -129,21 +142,38 @@ __device__ __forceinline__ void rows_of_ranks(const BatchParams &P, const CandDe
             if (adr > R || adc > R) continue;
             const int pidx = (R + dr) * P.k + (R + dc);
             const float nw = __fdiv_rn(psf_lds ? psf_lds[pidx] : P.psf[pidx], sum);
-            int slot;
             if (!(nw < lim)) {
-                slot = hz++;
                 // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
-                if (slot == 0) mn = j; else atomicMin(&efirst[j], mn);
-            } else slot = c.nnz - 1 - others++;
-            const int64_t e = ell_at(base, cd.N, slot);
-            P.ell_idx[e] = (uint16_t)j; P.ell_w[e] = nw;
+                if (hz == 0) mn = j; else atomicMin(&efirst[j], mn);
+                const int l = hz & 3;
+#pragma unroll
+                for (int t = 0; t < 4; t++) { fw[t] = l == t ? nw : fw[t]; fi[t] = l == t ? j : fi[t]; }
+                hz++;
+                if ((hz & 3) == 0) store_group((hz >> 2) - 1, fw, fi);
+            } else {
+                const int slot = c.nnz - 1 - others++;
+                const int l = slot & 3;
+#pragma unroll
+                for (int t = 0; t < 4; t++) { bw[t] = l == t ? nw : bw[t]; bi[t] = l == t ? j : bi[t]; }
+                if (l == 0) store_group(slot >> 2, bw, bi);
+            }
+        }
+        if (hz & 3) {                                    // the group where the two runs meet (or where the leading entries end)
+            const int l = hz & 3;
+            // lanes below l from the leading run; lanes from l on from the other run, whose buffer holds this group if there are
+            // others at all (their lowest slot is hz), else zeros
+            const bool back_here = others > 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (t >= l) { fw[t] = back_here ? bw[t] : 0.f; fi[t] = back_here ? bi[t] : 0; }
+            store_group(hz >> 2, fw, fi);
         }
         // padding (index 0, weight 0) up to the group count of the first position of this pixel's 64-position chunk (a
         // wavefront of the solve kernel reads the groups its first lane needs for all of its lanes): P.inv[chunk]
         const int kh = (int)P.inv[cd.crop_off + (pos >> 6)];
-        for (int sl = c.nnz; sl < 4 * kh; sl++) {
-            const int64_t e = ell_at(base, cd.N, sl);
-            P.ell_idx[e] = 0; P.ell_w[e] = 0.f;
+        {
+            const float zw[4] = {0.f, 0.f, 0.f, 0.f};
+            const int zi[4] = {0, 0, 0, 0};
+            for (int g = (c.nnz + 3) >> 2; g < kh; g++) store_group(g, zw, zi);
         }
         P.ell_meta[cd.crop_off + pos] = (uint32_t)c.nnz | ((uint32_t)hz << 16);
         hzmax = hz > hzmax ? hz : hzmax;

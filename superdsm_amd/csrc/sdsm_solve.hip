@@ -33,8 +33,8 @@ namespace {
 #define NEWTON_RELTOL 1e-6
 #define LS_ALPHA 0.01
 #define LS_BETA 0.5
-#define LS_K 8            // step lengths per line-search sweep
-#define LS_SWEEPS 5       // t0 * 2^-(8 s + k): down to 2^-39
+#define LS_K 4            // step lengths per line-search sweep (8 needed 3 % fewer sweeps at twice the loss evaluations per sweep: two thirds of all of a solve's loss evaluations were line-search ones)
+#define LS_SWEEPS 10      // t0 * 2^-(4 s + k): down to 2^-39
 #define LS_T0_ELL 4.0     // elliptical solves start far from the optimum: longer first step
 #if defined(SDSM_PROFILE) && defined(SDSM_PROFILE_FINE)
 #define FINE_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
@@ -466,8 +466,7 @@ __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, doubl
         double tk = t0;
 #pragma unroll
         for (int k = 0; k < LS_K; k++) {
-            // four independent loss evaluations in flight keep the FP64 pipe busy; all eight would double the live registers
-            if (k == LS_K / 2) __builtin_amdgcn_sched_barrier(0);
+            if (k == LS_K / 2) __builtin_amdgcn_sched_barrier(0);       // two independent loss evaluations in flight, not four (registers)
             const double t = a0 + tk * a1;
             ps[k] += softplus_neg(t);
             tk *= LS_BETA;
@@ -1263,7 +1262,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         if (!accepted) { status = 1; break; }               // stalled; psi still is the value at x
         for (int i = tid; i < n; i += L::WGS) x[i] += tbest * d[i];
         __syncthreads();
-        tprev = tbest;
+        tprev = uni(tbest);
         if (M > 0) {
             if (tbest >= 1) { mu *= MU_DECAY; mu = uni(mu < fresh(MU_MIN) ? 0 : mu); }
             else mu = 1.0;
