@@ -131,7 +131,7 @@ struct sdsm_plan {
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
     int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0, n_wide = 0;
-    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_pix_d = 0, off_tmp_rc = 0, off_inv = 0, off_ell_meta = 0,
+    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_ell_meta = 0,
            off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, off_ticket = 0, total = 0;
     // The launch lists and CandDesc.wide_* live in the workspace (sdsm_batch_upload): a layout change after the upload
     // (sdsm_plan_set_latency_mode) would leave stale tables on the device, so launches check the generation they were uploaded at.
@@ -236,7 +236,6 @@ static void layout_plan(sdsm_plan *p)
     p->off_crop_cc = take(4 * np);
     p->off_dist = take(4 * np);
     p->off_tmp_y = take(8 * np);
-    p->off_pix_d = take(8 * np);
     p->off_tmp_rc = take(4 * np);
     p->off_inv = take(4 * np);
     p->off_ell_meta = take(4 * np);
@@ -413,7 +412,7 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
     P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);
     P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
     P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_meta = (uint32_t *)(b + p->off_ell_meta);
-    P.tmp_y = (double *)(b + p->off_tmp_y); P.pix_d = (double *)(b + p->off_pix_d); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc); P.inv = (uint32_t *)(b + p->off_inv);
+    P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc); P.inv = (uint32_t *)(b + p->off_inv);
     P.hess_thr = SDSM_HESS_THR;
     P.psf = (const float *)(b + p->off_psf);
     P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);

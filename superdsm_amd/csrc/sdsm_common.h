@@ -8,8 +8,6 @@
 // compiler falls back to flat_load, whose results can only be awaited with vmcnt(0) (one load in flight at a time).
 #define SDSM_GLOBAL __attribute__((address_space(1)))
 typedef const double SDSM_GLOBAL *g_cdouble_p;
-typedef double SDSM_GLOBAL *g_double_p;
-typedef double SDSM_GLOBAL *g_double_p;
 typedef const float SDSM_GLOBAL *g_cfloat_p;
 typedef const uint32_t SDSM_GLOBAL *g_cu32_p;
 typedef const uint16_t SDSM_GLOBAL *g_cu16_p;
@@ -116,8 +114,7 @@ struct BatchParams {
     const int32_t *order;              // workgroup -> candidate (largest first)
     double *crop_y;                    // 8 B / pixel, final crop order (rows with the most G~ entries first)
     uint32_t *crop_rc;                 // (row << 16) | col, image coordinates: 4 B / pixel, final crop order
-    double *tmp_y;                     // setup: the crop in scan order (low-discrepancy scatter of the raster rank); solve: the loss derivative r of every pixel between the two loops of the sparse pass
-    double *pix_d;                     // solve: the loss curvature d of every pixel between the two loops of the sparse pass (8 B / pixel)
+    double *tmp_y;                     // setup only: the crop in scan order (low-discrepancy scatter of the raster rank)
     uint32_t *tmp_rc;                  // setup only
     uint32_t *crop_cc;                 // compressed coordinates (setup only, scan order)
     uint32_t *dist;                    // setup only: chessboard distance to the nearest grid point, then the final crop position

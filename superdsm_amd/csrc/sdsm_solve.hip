@@ -83,7 +83,6 @@ struct Lay {
 struct Cand {                       // per-candidate global pointers (already offset) and scalars
     g_cdouble_p crop_y;
     g_cu32_p crop_rc;
-    g_double_p pix_r, pix_d;            // per-pixel loss derivative / curvature between the loops of the sparse pass
     g_cf32x4_p ell_w4;                  // group j of position p: element j * N + p (4 weights)
     g_cu16x4_p ell_i4;                  // (4 column indices)
     g_cu32_p ell_meta;                  // row entries | Hessian entries << 16
@@ -139,7 +138,7 @@ __device__ __forceinline__ CandState uniform_state(const CandState &d)
 __device__ __forceinline__ Cand uniform_cand(const Cand &c)
 {
     Cand u;
-    u.crop_y = uni(c.crop_y); u.crop_rc = uni(c.crop_rc); u.pix_r = uni(c.pix_r); u.pix_d = uni(c.pix_d); u.ell_w4 = uni(c.ell_w4); u.ell_i4 = uni(c.ell_i4); u.ell_meta = uni(c.ell_meta);
+    u.crop_y = uni(c.crop_y); u.crop_rc = uni(c.crop_rc); u.ell_w4 = uni(c.ell_w4); u.ell_i4 = uni(c.ell_i4); u.ell_meta = uni(c.ell_meta);
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) u.gcount[j] = uni(c.gcount[j]);
     u.hglob = (double *)uni((unsigned long long)c.hglob);
@@ -664,15 +663,16 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
     __syncthreads();
     const int zm = M > 0 ? c.zmax : 0;
     const bool in_regs = zm <= ZREG;
-    // Two loops over the pixels, each with a small set of live registers (the kernel runs three wavefronts per SIMD):
-    // A: S, the loss terms, psi and the polynomial gradient sums; the derivative r and curvature d of every pixel are parked in
-    //    global memory (read back by the same thread: no synchronisation);
-    // B: the atomics -- gradient entries of xi (all row entries), Hessian entries (leading row entries) -- and the polynomial
-    //    Hessian sums.
+    // One loop over the pixels; the row of G~ is loaded TWICE per pixel -- for S, and again after the loss terms for the atomics
+    // (served by the caches) -- instead of being held in 42 registers across the loss evaluation: the kernel runs three
+    // wavefronts per SIMD (168 registers).
     {
-        double ra[7];                                    // add_moments' m[0 .. 6]
+        int rbt[6];                                      // the 6 dense theta rows (uniform)
 #pragma unroll
-        for (int k = 0; k < 7; k++) ra[k] = 0;
+        for (int b = 0; b < 6; b++) rbt[b] = __builtin_amdgcn_readfirstlane(rbp[M + b]);
+        double red[NMOM];                                // psi and the coordinate moments of r and d (add_moments)
+#pragma unroll
+        for (int k = 0; k < NMOM; k++) red[k] = 0;
         for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
             FINE_START();
             const double yv = c.crop_y[p];
@@ -680,46 +680,21 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
             const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
             double Sv = (u * u) * xv[0] + (v * v) * xv[1] + (2 * (u * v)) * xv[2] + (2 * u) * xv[3] + (2 * v) * xv[4] + xv[5];
             FINE_ADD(8);
-            if (M > 0) Sv += smooth_term(c, xv, p);
+            Sv += smooth_term(c, xv, p);
             FINE_ADD(9);
             double phi, r, dc;
             loss_terms(yv, Sv, &phi, &r, &dc);
-            ra[0] += phi;
-            ra[1] += r; ra[2] += r * u; ra[3] += r * v; ra[4] += r * (u * u); ra[5] += r * (u * v); ra[6] += r * (v * v);
-            c.pix_r[p] = r; c.pix_d[p] = dc;
+            add_moments(red, phi, r, dc, u, v);
             FINE_ADD(10);
-        }
-        block_sum_scatter<7, L::NWAVES>(ra, SD + L::RED);
-        if (tid < 7) tot[tid] = sum_scatter_total<7, L::NWAVES>(SD + L::RED, tid);
-    }
-    PROF_ADD(0, pt);
-    {
-        int rbt[6];                                      // the 6 dense theta rows (uniform)
-#pragma unroll
-        for (int b = 0; b < 6; b++) rbt[b] = __builtin_amdgcn_readfirstlane(rbp[M + b]);
-        double rh[15];                                   // add_moments' m[7 .. 21]
-#pragma unroll
-        for (int k = 0; k < 15; k++) rh[k] = 0;
-        for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
-            FINE_START();
-            const double dc = c.pix_d[p], r = c.pix_r[p];
-            const uint32_t rc = c.crop_rc[p];
-            const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-            {
-                const double uu = u * u, uv = u * v, vv = v * v;
-                const double duu = dc * uu, duv = dc * uv, dvv = dc * vv;
-                rh[0] += dc; rh[1] += dc * u; rh[2] += dc * v; rh[3] += duu; rh[4] += duv; rh[5] += dvv;
-                rh[6] += duu * u; rh[7] += duu * v; rh[8] += dvv * u; rh[9] += dvv * v;
-                rh[10] += duu * uu; rh[11] += duu * uv; rh[12] += duu * vv; rh[13] += dvv * uv; rh[14] += dvv * vv;
-            }
             if (dc != 0 || r != 0) {
                 const double q[6] = {u * u, v * v, 2 * (u * v), 2 * u, 2 * v, 1.0};
                 const uint32_t meta = c.ell_meta[p];
                 const int nnz = (int)(meta & 0xffffu), hnz = (int)(meta >> 16);
                 if (in_regs) {
+                    int p2 = p;
+                    asm volatile("" : "+v"(p2));          // (a second load, not the first one kept alive)
                     float w[ZREG]; RowIds ip;
-                    load_row(c, p, w, ip);
-                    FINE_ADD(8);
+                    load_row(c, p2, w, ip);
                     const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
 #pragma unroll
                     for (int j = SDSM_ELL_GROUPS_REG - 1; j >= 0; j--) {          // (the leading entries, groups 0 .. 2, are used again below)
@@ -772,8 +747,8 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
             }
             FINE_ADD(12);
         }
-        block_sum_scatter<15, L::NWAVES>(rh, SD + L::RED);            // (its barriers: every atomic of the pass has landed)
-        if (tid < 15) tot[7 + tid] = sum_scatter_total<15, L::NWAVES>(SD + L::RED, tid);
+        PROF_ADD(0, pt);
+        moments_total<L>(red, tot);                      // (its barriers: every atomic of the pass has landed)
     }
     {
         const double uh = fx_unit(c.fxh_hi), ug = fx_unit(c.fxg_hi);
@@ -1369,7 +1344,6 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         for (int i = tid; i < (cd.h * cd.w + 31) / 32; i += L::WGS) mk0[i] = 0;
     }
     c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
-    c.pix_r = (g_double_p)(P.tmp_y + cd.crop_off); c.pix_d = (g_double_p)(P.pix_d + cd.crop_off);
     c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = Mfull > 0 ? st.gcount[j] : 0;
@@ -1595,7 +1569,6 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     c.N = cd.N; c.zmax = M > 0 ? st.zmax : 0; c.hzmax = M > 0 ? st.hzmax : 0; c.env_size = efull;
     c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr; c.wtimeout = 0;
     c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
-    c.pix_r = (g_double_p)(P.tmp_y + cd.crop_off); c.pix_d = (g_double_p)(P.pix_d + cd.crop_off);
     c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
 #pragma unroll
     for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = M > 0 ? st.gcount[j] : 0;
@@ -1741,9 +1714,10 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     }
     // class 1 at THREE wavefronts per SIMD (168 registers; measured 6.54 vs 7.43 ms at two: the solver is latency bound and a third
     // workgroup per compute unit fills its stalls, at the price of ~35 spilled registers; four -- 128 registers -- spill 73: 10.9 ms)
-    // class 1 runs THREE wavefronts per SIMD (168 registers, no scratch: the sparse pass is split into two lean loops for that).
-    // Measured on the 8-image launch: 8.10 ms at two, 6.33 ms at three, 6.57 ms at four (128 registers: 36 spilled, in the
-    // line-search and atomics loops) -- the solver is latency bound and a third workgroup per compute unit fills its stalls.
+    // class 1 runs THREE wavefronts per SIMD (168 registers, no scratch: the sparse pass loads the row of G~ twice instead of
+    // holding it across the loss evaluation).  Measured on the 8-image launch: 7.4 ms at two wavefronts (240 registers), 5.5 ms at
+    // three, 6.6 ms at four (128 registers: 36 spilled, in the line-search and atomics loops) -- the solver is latency bound and a
+    // third workgroup per compute unit fills its stalls.
     if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
     if ((n_c > 0 || n_d > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;

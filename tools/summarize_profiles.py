@@ -19,7 +19,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(os.path.join(root, 'profiles'), exist_ok=True)
 stats = glob.glob(os.path.join(root, 'gpurun_out', f'{tag}_trace', '*', '*kernel_stats.csv'))
 if stats:
-    shutil.copy(stats[0], os.path.join(root, 'profiles', f'{tag}_kernel_stats.csv'))
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(root, 'profiles', f'{tag}_kernel_stats.csv'))
 
 
 def per_kernel(pattern, counter):
@@ -27,7 +27,7 @@ def per_kernel(pattern, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
     if not files:
         return {}
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         if r['Counter_Name'] != counter:
             continue
         k = r['Kernel_Name'].split('(')[0][:80]
@@ -63,7 +63,7 @@ sq = {}
 files = glob.glob(os.path.join(root, 'gpurun_out', f'{tag}_sq', '*', '*counter_collection.csv'))
 if files:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         if 'sdsm_k_solve<128' in r['Kernel_Name']:
             agg['solve class 1'][r['Counter_Name']].append(float(r['Counter_Value']))
         elif 'sdsm_k_setup' in r['Kernel_Name']:
