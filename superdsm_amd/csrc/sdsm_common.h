@@ -22,7 +22,7 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 // limits of this implementation (DESIGN.md "Limits")
 #define SDSM_MAX_LABELS 65535      // footprint bitset in LDS
 #define SDSM_MAX_BBOX_DIM 4096     // row / column rank tables in LDS
-#define SDSM_PSF_LDS 4352           // words of LDS shared by the footprint bitset (2048) and the PSF table (k <= 65)
+#define SDSM_PSF_LDS 4256           // words of LDS shared by the footprint bitset (2048) and the PSF table (k <= 65)
 #define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
 #define SDSM_K1_NMAX 128           // solve class 1: 6 + M <= 128 and envelope <= SDSM_K1_EMAX doubles (LDS ~ 30 KB)
 #define SDSM_K1_EMAX 2560

@@ -69,8 +69,8 @@ __device__ float pw_block(WeightCtx &c, int lo, int n)
 __device__ float pw_sum(WeightCtx &c, int M)
 {
     if (M <= 128) return pw_block(c, 0, M);
-    int s_lo[16], s_n[16], s_stage[16];
-    float s_left[16];
+    int s_lo[6], s_n[6], s_stage[6];                     // M <= SDSM_MAX_GRID = 2048: at most 5 levels above the 128-element blocks
+    float s_left[6];
     int sp = 0;
     s_lo[0] = 0; s_n[0] = M; s_stage[0] = 0; s_left[0] = 0.f;
     float ret = 0.f;
