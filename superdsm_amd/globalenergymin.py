@@ -182,17 +182,25 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         obj = Object()
         obj.footprint = {label}
         atoms.append(obj)
-    out.write('\nIteration 1:')
-    solve(atoms, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 1), out=out, shard=shard)
-    atom_by_label = {next(iter(a.footprint)): a for a in atoms}
-
     universes = []
     for cluster in adjacencies.cluster_labels:
         obj = Object()
         obj.footprint = set(adjacencies.get_atoms_in_cluster(cluster))
         universes.append(obj)
-    solve(universes, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 0),
-          ('Computing universe costs', 'Universe costs computed'), out=out, shard=shard)
+    out.write('\nIteration 1:')
+    if solver is None and shard is None and getattr(compute_objects, '__module__', None) == Object.__module__:   # (not when a test substitutes the operator)
+        # the atoms and the cluster universes do not depend on each other (globalenergymin.py:192,199 computes them one after the
+        # other): ONE batch of the engine -- a generation batch costs a round trip to the GPU whatever its size
+        muted = out.derive(muted=True)
+        fallbacks = compute_objects_multi([(atoms, y_img, atoms_map), (universes, y_img, atoms_map)], dsm_cfg,
+                                          [_generation_log_dir(log_root_dir, 1), _generation_log_dir(log_root_dir, 0)], out=muted)
+        for objs, fb, line in ((atoms, fallbacks[0], 'Computed objects'), (universes, fallbacks[1], 'Universe costs computed')):
+            out.write(f'{line}: {len(objs)} ({fb}x fallback)')
+    else:
+        solve(atoms, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 1), out=out, shard=shard)
+        solve(universes, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 0),
+              ('Computing universe costs', 'Universe costs computed'), out=out, shard=shard)
+    atom_by_label = {next(iter(a.footprint)): a for a in atoms}
 
     solved_directly, trivial = set(), set()        # Criterion 2 / universes of one or two atoms
     for cluster, universe in zip(adjacencies.cluster_labels, universes):
@@ -223,9 +231,10 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         while True:
             number = 1 + len(generations)
             out.write('')
-            done, todo = progress(solved_directly)
-            text = 'progress unknown' if np.isnan(done) or np.isnan(todo) else f'(finished {100 * done / (todo + done):.0f}% or more)'
-            out.write(f'Iteration {number}: {Text.style(text, Text.BOLD)}')
+            if not getattr(out, 'muted', False):               # the estimate enumerates everything that is left: only for the log line
+                done, todo = progress(solved_directly)         # (it cannot raise here: what is left only shrinks after the calls above)
+                text = 'progress unknown' if np.isnan(done) or np.isnan(todo) else f'(finished {100 * done / (todo + done):.0f}% or more)'
+                out.write(f'Iteration {number}: {Text.style(text, Text.BOLD)}')
             new_generation, new_objects = _process_generation(
                 cover, objects, generations[-1], y_img, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
                 _generation_log_dir(log_root_dir, number), pruning, solved_directly, out, shard=shard, solver=solver)

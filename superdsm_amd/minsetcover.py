@@ -125,7 +125,9 @@ class MinSetCover:
         self.beta = beta
         self.adjacencies = adjacencies
         self.solve_minsetcover_kwargs = solve_minsetcover_kwargs
-        self.objects_by_cluster = {cl: [a for a in atoms if adjacencies.get_cluster_label(label_of(a)) == cl] for cl in adjacencies.cluster_labels}
+        self.objects_by_cluster = {cl: [] for cl in adjacencies.cluster_labels}
+        for a in atoms:                                     # (one pass; the reference filters the atoms once per cluster: same lists, same order)
+            self.objects_by_cluster[adjacencies.get_cluster_label(label_of(a))].append(a)
         self.solution_by_cluster = {cl: self.objects_by_cluster[cl] for cl in adjacencies.cluster_labels}
 
     def get_atom(self, atom_label):

@@ -248,6 +248,7 @@ def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT
     jobs = [(list(objs), y, atoms) for objs, y, atoms in jobs]
     todo = [j for j, (objs, _, _) in enumerate(jobs) if len(objs)]
     total = fb = 0
+    per_job = [0] * len(jobs)                               # fallbacks of every job (returned)
     for g0 in range(0, len(todo), 16):
         group = todo[g0:g0 + 16]
         images = [device_image(jobs[j][1], jobs[j][2], margin) for j in group]
@@ -264,7 +265,9 @@ def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT
             rec, frs = records[pos:pos + len(objs)], fragments[pos:pos + len(objs)]
             if log_root_dirs is not None and log_root_dirs[j] is not None:
                 _write_logs(log_root_dirs[j], rec)
-            fb += _assign(objs, rec, frs, dt * len(objs) / len(fps))
+            per_job[j] = _assign(objs, rec, frs, dt * len(objs) / len(fps))
+            fb += per_job[j]
             pos += len(objs)
             total += len(objs)
     out.write(f'{status_line[1]}: {total} ({fb}x fallback)')
+    return per_job
