@@ -17,7 +17,8 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
-extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w);
+extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w, int cls);
+extern "C" int sdsm_setup_class(int max_dim, int max_mcap, int max_label, int k);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -125,6 +126,7 @@ struct sdsm_plan {
     std::vector<CandDesc> cand;
     std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those whose bound on M admits more than solve class 1, then more than class 2
     int n_order_c = 0, n_order_d = 0, n_order_w = 0;   // the last list: (candidate | member << 24) of the workgroup groups
+    int setup_class = 2;         // LDS limits of the setup kernel that hold this plan (sdsm_setup_class)
     int mode = 0;                // sdsm_plan_set_latency_mode: 0 throughput, 1 latency, 2 no workgroup groups
     int wide_pixels = INT_MAX;   // throughput mode by default
     std::vector<float> psf;
@@ -311,6 +313,12 @@ extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, con
         p->mask_info[4 * i] = r0; p->mask_info[4 * i + 1] = c0; p->mask_info[4 * i + 2] = c.h; p->mask_info[4 * i + 3] = c.w;
         p->mask_off_bytes[i] = c.mask_off * 4; p->xi_off[i] = c.xi_off; p->n_pixels[i] = c.N;
     }
+    {
+        int max_dim = 1, max_mcap = 1, max_label = 1;
+        for (const CandDesc &c : p->cand) { max_dim = std::max(max_dim, std::max(c.h, c.w)); max_mcap = std::max(max_mcap, c.Mcap); }
+        for (int im = 0; im < n_images; im++) max_label = std::max(max_label, n_atoms[im]);
+        p->setup_class = sdsm_setup_class(max_dim, max_mcap, max_label, p->k);
+    }
     layout_plan(p);
     return p;
 }
@@ -460,7 +468,7 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
     for (size_t i = 0; i < p->images.size(); i++) { P.img[i].y = d_y[i]; P.img[i].atoms = d_atoms[i]; P.img[i].valid = d_valid[i]; }
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    if ((e = sdsm_launch_setup(P, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch setup");
+    if ((e = sdsm_launch_setup(P, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w, p->setup_class)) != hipSuccess) return hipfail(e, "launch setup");
     if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     hipStream_t s1 = nullptr, s2 = nullptr;
     hipEvent_t *fj = nullptr;
