@@ -198,15 +198,15 @@ __device__ __forceinline__ int envelope_from_first(const BatchParams &P, const C
 }  // namespace
 
 // Limits of the setup kernel's LDS tables: the host picks the smallest class that holds the plan (sdsm_setup_class).
-struct SetupLimS { static constexpr int DIM = 512, GRID = 512, PSFW = 1152, LABELS = 32767; };      // 13 KB: PSF k <= 33
-struct SetupLimM { static constexpr int DIM = 1024, GRID = 1024, PSFW = SDSM_PSF_LDS, LABELS = SDSM_MAX_LABELS; };   // 30 KB: PSF k <= 65
-struct SetupLimL { static constexpr int DIM = SDSM_MAX_BBOX_DIM, GRID = SDSM_MAX_GRID, PSFW = SDSM_PSF_LDS, LABELS = SDSM_MAX_LABELS; };   // 54 KB
+struct SetupLimS { static constexpr int DIM = 512, GRID = 512, PSFW = 1152, LABELS = 32767, WPE = 4; };      // 13 KB: PSF k <= 33
+struct SetupLimM { static constexpr int DIM = 1024, GRID = 1024, PSFW = SDSM_PSF_LDS, LABELS = SDSM_MAX_LABELS, WPE = 4; };   // 30 KB: PSF k <= 65
+struct SetupLimL { static constexpr int DIM = SDSM_MAX_BBOX_DIM, GRID = SDSM_MAX_GRID, PSFW = SDSM_PSF_LDS, LABELS = SDSM_MAX_LABELS, WPE = 3; };   // 54 KB
 
 // LDS of the setup kernel is sized by the limits T of a plan's class (SetupLimits below, chosen by the host from the plan's
 // largest bounding box, bound on M, label and PSF): the common plans -- regions of a few hundred pixels across -- then run four
 // workgroups per compute unit instead of the two that the largest tables allow (1.58 -> 1.22 ms on the 8-image launch).
 template <class T>
-__global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup(BatchParams P)
+__global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
 {
     static_assert((T::LABELS + 1) / 32 <= T::PSFW && T::DIM % 32 == 0, "setup limits");
     // footprint bitset during the region scan, then the PSF table (k * k floats, if it fits) for the rows of G~
