@@ -12,7 +12,7 @@ files = glob.glob(os.path.join(root, 'gpurun_out', f'{tag}_trace', '*', '*kernel
 rows = [r for r in csv.DictReader(open(max(files, key=os.path.getmtime))) if 'sdsm' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 t0 = int(rows[0]['Start_Timestamp'])
-last = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('sdsm_k_setup')][-4:]
+last = [i for i, r in enumerate(rows) if 'sdsm_k_setup' in r['Kernel_Name'] and 'rows' not in r['Kernel_Name']][-4:]
 lines = ['kernel trace of `python3 bench.py --no-cpu --no-extras --steps 6 --warmup 2 --repeats 2` (rocprofv3 --kernel-trace), times in ms since the first sdsm kernel;',
          'one step = sdsm_k_setup, then the size classes of sdsm_k_solve concurrently (class 1 does the work here; the lists of classes 2 and 3 are upper bounds whose workgroups exit at once and wait for free compute units)', '']
 for r in rows[last[0]:]:
