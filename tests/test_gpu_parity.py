@@ -1258,3 +1258,28 @@ def test_launches_reproduce_their_results_bit_for_bit(gpu):
             assert rec2[2 * i].tobytes() == runs[0][0][i].tobytes() == rec2[2 * i + 1].tobytes(), (workload, i)
             for k in range(2):
                 assert tuple(fr2[2 * i + k][0]) == tuple(fr1[i][0]) and np.array_equal(fr2[2 * i + k][1], fr1[i][1])
+
+
+@pytest.mark.parametrize('factor', [2.0 ** -40, 2.0 ** -10, 8.0])
+def test_intensity_scale_does_not_matter_for_the_fixed_point_sums(gpu, factor):
+    """The solve kernel accumulates the scattered gradient / Hessian contributions as integers in units chosen per candidate from
+    the exponent of max|y| (sdsm_k_setup: CandState.yexp).  psi = sum log(1 + exp(-y S)) only sees the products y S: an image
+    scaled by a constant -- 16-bit raw intensities, or tiny ones -- has the same regions, and the same optima up to the scale of
+    the parameters and to the regulariser (which does not scale): GPU and CPU oracle must agree on the scaled image as they do on
+    the unscaled one.  (Scales of 64 and more -- raw 16-bit intensities -- are outside the solver's domain: the regulariser then
+    hardly matters, the approximate Hessian of DESIGN.md section 4 converges slowly and oracle and GPU both stop at the iteration cap;
+    the reference normalises images to [0, 1], pipeline.py:192.)"""
+    from oracle import oracle
+    from superdsm_amd import testing
+    scene = testing.make_scene('synthetic256', max_size=2)
+    scene = dict(scene, y=scene['y'] * factor)
+    res = testing.solve_scene_gpu(scene)
+    recs, frags = res['records'], res['fragments']
+    orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], scene['footprints'], scene['dsm_cfg'], nthreads=0)
+    np.testing.assert_array_equal(recs['n_pixels'], orecs['N'])
+    np.testing.assert_array_equal(recs['n_deform'], orecs['M'])
+    for k in range(len(scene['footprints'])):
+        assert recs['status'][k] == orecs['status'][k], (k, recs['status'][k], orecs['status'][k])
+        tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
+        assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (k, recs['energy'][k], orecs['energy'][k])
+        assert testing.dice(frags[k][0], frags[k][1], orecs['fg_offset'][k], ofrags[k], scene['y'].shape) >= 0.999
