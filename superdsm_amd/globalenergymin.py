@@ -188,14 +188,11 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         obj.footprint = set(adjacencies.get_atoms_in_cluster(cluster))
         universes.append(obj)
     out.write('\nIteration 1:')
-    if solver is None and shard is None and getattr(compute_objects, '__module__', None) == Object.__module__:   # (not when a test substitutes the operator)
+    if shard is None and log_root_dir is None and getattr(compute_objects, '__module__', None) == Object.__module__:   # (not when a test substitutes the operator)
         # the atoms and the cluster universes do not depend on each other (globalenergymin.py:192,199 computes them one after the
-        # other): ONE batch of the engine -- a generation batch costs a round trip to the GPU whatever its size
-        muted = out.derive(muted=True)
-        fallbacks = compute_objects_multi([(atoms, y_img, atoms_map), (universes, y_img, atoms_map)], dsm_cfg,
-                                          [_generation_log_dir(log_root_dir, 1), _generation_log_dir(log_root_dir, 0)], out=muted)
-        for objs, fb, line in ((atoms, fallbacks[0], 'Computed objects'), (universes, fallbacks[1], 'Universe costs computed')):
-            out.write(f'{line}: {len(objs)} ({fb}x fallback)')
+        # other): ONE batch of the engine -- a batch costs a round trip to the GPU whatever its size.  (With per-candidate log
+        # files the two keep their own batches: their logs go to different directories.)
+        solve(atoms + universes, y_img, atoms_map, dsm_cfg, None, ('Computing objects and universe costs', 'Computed objects and universe costs'), out=out)
     else:
         solve(atoms, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 1), out=out, shard=shard)
         solve(universes, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 0),
