@@ -112,14 +112,37 @@ def _iterate_generation(previous_generation, adjacencies, max_seed_distance, get
                 yield item, grown, new_atom
 
 
-def _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=DEFAULT_MAX_WORK_AMOUNT,
-                       ignored_cluster_labels=frozenset(), skip_last=False):
+def _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amount=DEFAULT_MAX_WORK_AMOUNT, skip_last=False):
+    """Footprints still to be enumerated after the last generation, per cluster (a footprint never leaves its cluster)."""
     current = [c.footprint for c in generations[-1]]
-    remaining = 0
+    remaining = {}
+    total = 0
     while current:
-        current = [fp for _, fp, _ in _iterate_generation(current, adjacencies, max_seed_distance,
-                                                          ignored_cluster_labels=ignored_cluster_labels, skip_last=skip_last)]
-        remaining += len(current)
+        current = [fp for _, fp, _ in _iterate_generation(current, adjacencies, max_seed_distance, skip_last=skip_last)]
+        for fp in current:
+            cl = adjacencies.get_cluster_label(next(iter(fp)))
+            remaining[cl] = remaining.get(cl, 0) + 1
+        total += len(current)
+        if total > max_amount:                              # (what the first of the reference's two enumerations would see: clusters of <= 2 atoms have nothing to enumerate)
+            raise ValueError('estimated work amount is too large')
+    return remaining
+
+
+def _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=DEFAULT_MAX_WORK_AMOUNT,
+                       ignored_cluster_labels=frozenset(), skip_last=False, by_cluster=None):
+    """``(finished, remaining)`` (globalenergymin.py:310-323).  ``by_cluster``: the result of :func:`_remaining_by_cluster` for the
+    same state (one enumeration serves several sets of ignored clusters)."""
+    if by_cluster is None:
+        current = [c.footprint for c in generations[-1]]
+        remaining = 0
+        while current:
+            current = [fp for _, fp, _ in _iterate_generation(current, adjacencies, max_seed_distance,
+                                                              ignored_cluster_labels=ignored_cluster_labels, skip_last=skip_last)]
+            remaining += len(current)
+            if remaining > max_amount:
+                raise ValueError('estimated work amount is too large')
+    else:
+        remaining = sum(n for cl, n in by_cluster.items() if cl not in ignored_cluster_labels)
         if remaining > max_amount:
             raise ValueError('estimated work amount is too large')
     return sum(len(gen) for gen in generations), remaining
@@ -219,9 +242,12 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
     objects = atoms + universes
     progress = lambda ignored: _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=max_work_amount,
                                                   ignored_cluster_labels=ignored, skip_last=True)
-    performance.nontrivial_object_count = progress(trivial)[1]
+    by_cluster = _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amount=max_work_amount, skip_last=True)
+    first = lambda ignored: _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=max_work_amount,
+                                               ignored_cluster_labels=ignored, skip_last=True, by_cluster=by_cluster)
+    performance.nontrivial_object_count = first(trivial)[1]      # (one enumeration for both counts: a footprint stays in its cluster)
     performance.overall_object_count = performance.nontrivial_object_count + len(objects)
-    performance.iterative_object_count = progress(solved_directly)[1]
+    performance.iterative_object_count = first(solved_directly)[1]
     performance.overall_computed_object_count = len(objects)
 
     if len(solved_directly) < len(adjacencies.cluster_labels):
