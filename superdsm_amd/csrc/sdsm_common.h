@@ -252,6 +252,35 @@ __device__ __forceinline__ int block_min_i32(int v, int *scratch)
     return r;
 }
 
+// The same for FOUR consecutive chunks of the workgroup's size at once (element k of thread t is item k * SDSM_WG + t): one pair of
+// barriers per four chunks.  pos[k] = number of set flags before the thread's item of chunk k; *total = all set flags.
+__device__ __forceinline__ void block_excl_count4(const bool (&flag)[4], int *scratch /* 4 * SDSM_WAVES ints */, int (&pos)[4], int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long m[4];
+    int within[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { m[k] = __ballot(flag[k]); within[k] = __popcll(m[k] & ((1ull << lane) - 1ull)); }
+    __syncthreads();
+    if (lane < 4) {
+        unsigned long long mk = m[0];
+#pragma unroll
+        for (int k = 1; k < 4; k++) mk = lane == k ? m[k] : mk;
+        scratch[lane * SDSM_WAVES + wave] = __popcll(mk);
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < SDSM_WAVES; i++) { const int c = scratch[k * SDSM_WAVES + i]; if (i < wave) before += c; tot += c; }
+        pos[k] = run + before + within[k];
+        run += tot;
+    }
+    *total = run;
+}
+
 // Exclusive prefix count of `flag` over the workgroup in thread order; *total = number of set flags.
 __device__ __forceinline__ int block_excl_count(bool flag, int *scratch /* SDSM_WAVES ints */, int *total)
 {

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __shared__ uint32_t gridkeys[T::GRID];
     __shared__ unsigned long long mom[4];
     __shared__ unsigned long long scr64[SDSM_WAVES];
-    __shared__ int scr32[SDSM_WAVES];
+    __shared__ int scr32[SDSM_WAVES], scr32x4[4 * SDSM_WAVES];
     __shared__ int sh_M, sh_npos, sh_nneg, sh_err, sh_yhi;
     __shared__ int cls_cnt[SDSM_MAX_ELL_GROUPS + 1], cls_start[SDSM_MAX_ELL_GROUPS + 1], cls_run[SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int wave_cnt[SDSM_WAVES][SDSM_MAX_ELL_GROUPS + 1];
@@ -260,37 +260,47 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     int running = 0;
     unsigned long long m_r = 0, m_c = 0, m_rr = 0, m_cc = 0;
     int npos = 0, nneg = 0, yhi = 0;                      // yhi: high word of the largest |y| (non-negative doubles order like their bits)
-    for (int base = 0; base < area; base += SDSM_WG) {
-        int i = base + tid;
-        bool flag = false;
-        int r = 0, c = 0;
-        double yv = 0;
-        if (i < area) {
-            r = i / cd.w; c = i - r * cd.w;
-            size_t p = (size_t)(cd.r0 + r) * im.W + (cd.c0 + c);
-            int a = atoms[p];
-            flag = a >= 1 && a <= T::LABELS && ((fpbits[a >> 5] >> (a & 31)) & 1u) && valid[p];
-            if (flag) yv = y[p];
-        }
-        int total;
-        int pos = block_excl_count(flag, scr32, &total);
-        if (flag) {
-            // scan order: low-discrepancy scatter of the raster rank (neighbouring positions are far apart in the image,
-            // which decorrelates the LDS atomics of the sparse Hessian accumulation in the solve kernel); the final
-            // crop order (step 4b) is this order, stably sorted by the size of the pixel's G~ row
-            int64_t o = cd.crop_off + (int64_t)(((unsigned long long)(running + pos) * cd.perm_inv) % (unsigned long long)cd.N);
-            if (running + pos < cd.N) {
-                P.tmp_y[o] = yv;
-                P.tmp_rc[o] = ((uint32_t)(cd.r0 + r) << 16) | (uint32_t)(cd.c0 + c);
+    for (int base = 0; base < area; base += 4 * SDSM_WG) {      // four chunks of 256 pixels per pair of barriers (block_excl_count4)
+        bool flag[4];
+        int rr[4], cc4[4];
+        double yv4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + k * SDSM_WG + tid;
+            flag[k] = false; rr[k] = 0; cc4[k] = 0; yv4[k] = 0;
+            if (i < area) {
+                const int r = i / cd.w, c = i - r * cd.w;
+                const size_t p = (size_t)(cd.r0 + r) * im.W + (cd.c0 + c);
+                const int a = atoms[p];
+                flag[k] = a >= 1 && a <= T::LABELS && ((fpbits[a >> 5] >> (a & 31)) & 1u) && valid[p];
+                if (flag[k]) yv4[k] = y[p];
+                rr[k] = r; cc4[k] = c;
             }
-            atomicOr(&rowbits[r >> 5], 1u << (r & 31));
-            atomicOr(&colbits[c >> 5], 1u << (c & 31));
-            const int ah = __double2hiint(yv) & 0x7fffffff;
-            yhi = ah > yhi ? ah : yhi;
-            if (yv < 0) nneg++;
-            if (yv > 0) {
-                unsigned long long rr = cd.r0 + r, cc = cd.c0 + c;
-                npos++; m_r += rr; m_c += cc; m_rr += rr * rr; m_cc += cc * cc;
+        }
+        int total, pos4[4];
+        block_excl_count4(flag, scr32x4, pos4, &total);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (flag[k]) {
+                const int r = rr[k], c = cc4[k], pos = pos4[k];
+                const double yv = yv4[k];
+                // scan order: low-discrepancy scatter of the raster rank (neighbouring positions are far apart in the image,
+                // which decorrelates the LDS atomics of the sparse Hessian accumulation in the solve kernel); the final
+                // crop order (step 4b) is this order, stably sorted by the size of the pixel's G~ row
+                int64_t o = cd.crop_off + (int64_t)(((unsigned long long)(running + pos) * cd.perm_inv) % (unsigned long long)cd.N);
+                if (running + pos < cd.N) {
+                    P.tmp_y[o] = yv;
+                    P.tmp_rc[o] = ((uint32_t)(cd.r0 + r) << 16) | (uint32_t)(cd.c0 + c);
+                }
+                atomicOr(&rowbits[r >> 5], 1u << (r & 31));
+                atomicOr(&colbits[c >> 5], 1u << (c & 31));
+                const int ah = __double2hiint(yv) & 0x7fffffff;
+                yhi = ah > yhi ? ah : yhi;
+                if (yv < 0) nneg++;
+                if (yv > 0) {
+                    unsigned long long rq = cd.r0 + r, cq = cd.c0 + c;
+                    npos++; m_r += rq; m_c += cq; m_rr += rq * rq; m_cc += cq * cq;
+                }
             }
         }
         running += total;
@@ -361,16 +371,17 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
         P.dist[cd.crop_off + i] = d;
     }
     bool unsupported = false;
-    for (;;) {
-        // smallest distance >= subsample; ties -> first pixel in raster order of the compressed mask
-        unsigned long long best = ~0ull;
-        for (int i = tid; i < cd.N; i += SDSM_WG) {
-            uint32_t d = P.dist[cd.crop_off + i];
-            if (d >= (uint32_t)S) {
-                unsigned long long key = ((unsigned long long)d << 32) | P.crop_cc[cd.crop_off + i];
-                best = key < best ? key : best;
-            }
+    // smallest distance >= subsample; ties -> first pixel in raster order of the compressed mask.  ONE pass over the pixels per
+    // added grid point: the pass that lowers the distances to the new point also finds the next candidate.
+    unsigned long long best = ~0ull;
+    for (int i = tid; i < cd.N; i += SDSM_WG) {
+        uint32_t d = P.dist[cd.crop_off + i];
+        if (d >= (uint32_t)S) {
+            unsigned long long key = ((unsigned long long)d << 32) | P.crop_cc[cd.crop_off + i];
+            best = key < best ? key : best;
         }
+    }
+    for (;;) {
         best = block_min_u64(best, scr64);
         if (best == ~0ull) break;
         if (M >= cap) { unsupported = true; break; }
@@ -378,10 +389,16 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
         if (tid == 0) gridkeys[M] = nk;
         M++;
         int nr = nk >> 16, nc = nk & 0xffffu;
+        best = ~0ull;
         for (int i = tid; i < cd.N; i += SDSM_WG) {
-            uint32_t key = P.crop_cc[cd.crop_off + i];
-            uint32_t t = (uint32_t)cheb(key >> 16, key & 0xffffu, nr, nc);
-            if (t < P.dist[cd.crop_off + i]) P.dist[cd.crop_off + i] = t;
+            const uint32_t key = P.crop_cc[cd.crop_off + i];
+            const uint32_t t = (uint32_t)cheb(key >> 16, key & 0xffffu, nr, nc);
+            uint32_t d = P.dist[cd.crop_off + i];
+            if (t < d) { d = t; P.dist[cd.crop_off + i] = t; }
+            if (d >= (uint32_t)S) {
+                unsigned long long k2 = ((unsigned long long)d << 32) | key;
+                best = k2 < best ? k2 : best;
+            }
         }
     }
     if (unsupported) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
