@@ -271,9 +271,11 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
             if (i < area) {
                 const int r = i / cd.w, c = i - r * cd.w;
                 const size_t p = (size_t)(cd.r0 + r) * im.W + (cd.c0 + c);
-                const int a = atoms[p];
-                flag[k] = a >= 1 && a <= T::LABELS && ((fpbits[a >> 5] >> (a & 31)) & 1u) && valid[p];
-                if (flag[k]) yv4[k] = y[p];
+                const int a = atoms[p];                           // three independent loads (not: label -> validity -> y, a chain of round trips)
+                const uint8_t vl = valid[p];
+                const double yl = y[p];
+                flag[k] = a >= 1 && a <= T::LABELS && ((fpbits[a >> 5] >> (a & 31)) & 1u) && vl;
+                if (flag[k]) yv4[k] = yl;
                 rr[k] = r; cc4[k] = c;
             }
         }
