@@ -222,6 +222,7 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[K], double *scratch)
     for (int k = 0; k < K; k++) v[k] = sum_scatter_total<K, WAVES>(scratch, k);
 }
 
+template <int WAVES = SDSM_WAVES>
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, unsigned long long *scratch)
 {
 #pragma unroll
@@ -234,7 +235,7 @@ __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v
     __syncthreads();
     unsigned long long r = scratch[0];
 #pragma unroll
-    for (int i = 1; i < SDSM_WAVES; i++) r = scratch[i] < r ? scratch[i] : r;
+    for (int i = 1; i < WAVES; i++) r = scratch[i] < r ? scratch[i] : r;
     return r;
 }
 
@@ -252,9 +253,10 @@ __device__ __forceinline__ int block_min_i32(int v, int *scratch)
     return r;
 }
 
-// The same for FOUR consecutive chunks of the workgroup's size at once (element k of thread t is item k * SDSM_WG + t): one pair of
+// The same for FOUR consecutive chunks of the workgroup's size at once (element k of thread t is item k * 64 * WAVES + t): one pair of
 // barriers per four chunks.  pos[k] = number of set flags before the thread's item of chunk k; *total = all set flags.
-__device__ __forceinline__ void block_excl_count4(const bool (&flag)[4], int *scratch /* 4 * SDSM_WAVES ints */, int (&pos)[4], int *total)
+template <int WAVES = SDSM_WAVES>
+__device__ __forceinline__ void block_excl_count4(const bool (&flag)[4], int *scratch /* 4 * WAVES ints */, int (&pos)[4], int *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long m[4];
@@ -266,7 +268,7 @@ __device__ __forceinline__ void block_excl_count4(const bool (&flag)[4], int *sc
         unsigned long long mk = m[0];
 #pragma unroll
         for (int k = 1; k < 4; k++) mk = lane == k ? m[k] : mk;
-        scratch[lane * SDSM_WAVES + wave] = __popcll(mk);
+        scratch[lane * WAVES + wave] = __popcll(mk);
     }
     __syncthreads();
     int run = 0;
@@ -274,7 +276,7 @@ __device__ __forceinline__ void block_excl_count4(const bool (&flag)[4], int *sc
     for (int k = 0; k < 4; k++) {
         int before = 0, tot = 0;
 #pragma unroll
-        for (int i = 0; i < SDSM_WAVES; i++) { const int c = scratch[k * SDSM_WAVES + i]; if (i < wave) before += c; tot += c; }
+        for (int i = 0; i < WAVES; i++) { const int c = scratch[k * WAVES + i]; if (i < wave) before += c; tot += c; }
         pos[k] = run + before + within[k];
         run += tot;
     }

@@ -198,15 +198,15 @@ __device__ __forceinline__ int envelope_from_first(const BatchParams &P, const C
 }  // namespace
 
 // Limits of the setup kernel's LDS tables: the host picks the smallest class that holds the plan (sdsm_setup_class).
-struct SetupLimS { static constexpr int DIM = 512, GRID = 512, PSFW = 1152, LABELS = 32767, WPE = 4; };      // 13 KB: PSF k <= 33
-struct SetupLimM { static constexpr int DIM = 1024, GRID = 1024, PSFW = SDSM_PSF_LDS, LABELS = SDSM_MAX_LABELS, WPE = 4; };   // 30 KB: PSF k <= 65
-struct SetupLimL { static constexpr int DIM = SDSM_MAX_BBOX_DIM, GRID = SDSM_MAX_GRID, PSFW = SDSM_PSF_LDS, LABELS = SDSM_MAX_LABELS, WPE = 3; };   // 54 KB
+struct SetupLimS { static constexpr int DIM = 512, GRID = 512, PSFW = 1152, LABELS = 32767, WPE = 4, WG = 256; };      // 13 KB: PSF k <= 33
+struct SetupLimM { static constexpr int DIM = 1024, GRID = 1024, PSFW = SDSM_PSF_LDS, LABELS = SDSM_MAX_LABELS, WPE = 4, WG = 1024; };   // 37 KB: PSF k <= 65; plans with regions this large have few candidates: 1024 threads each
+struct SetupLimL { static constexpr int DIM = SDSM_MAX_BBOX_DIM, GRID = SDSM_MAX_GRID, PSFW = SDSM_PSF_LDS, LABELS = SDSM_MAX_LABELS, WPE = 4, WG = 1024; };   // 54 KB
 
 // LDS of the setup kernel is sized by the limits T of a plan's class (SetupLimits below, chosen by the host from the plan's
 // largest bounding box, bound on M, label and PSF): the common plans -- regions of a few hundred pixels across -- then run four
 // workgroups per compute unit instead of the two that the largest tables allow (1.58 -> 1.22 ms on the 8-image launch).
 template <class T>
-__global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
+__global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
 {
     static_assert((T::LABELS + 1) / 32 <= T::PSFW && T::DIM % 32 == 0, "setup limits");
     // footprint bitset during the region scan, then the PSF table (k * k floats, if it fits) for the rows of G~
@@ -216,11 +216,11 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __shared__ uint16_t rowrank[T::DIM], colrank[T::DIM];
     __shared__ uint32_t gridkeys[T::GRID];
     __shared__ unsigned long long mom[4];
-    __shared__ unsigned long long scr64[SDSM_WAVES];
-    __shared__ int scr32[SDSM_WAVES], scr32x4[4 * SDSM_WAVES];
+    __shared__ unsigned long long scr64[(T::WG / 64)];
+    __shared__ int scr32[(T::WG / 64)], scr32x4[4 * (T::WG / 64)];
     __shared__ int sh_M, sh_npos, sh_nneg, sh_err, sh_yhi;
     __shared__ int cls_cnt[SDSM_MAX_ELL_GROUPS + 1], cls_start[SDSM_MAX_ELL_GROUPS + 1], cls_run[SDSM_MAX_ELL_GROUPS + 1];
-    __shared__ int wave_cnt[SDSM_WAVES][SDSM_MAX_ELL_GROUPS + 1];
+    __shared__ int wave_cnt[(T::WG / 64)][SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int efirst[T::GRID < SDSM_MAX_N_SOLVE ? T::GRID : SDSM_MAX_N_SOLVE];   // envelope of the solver's Hessian: first coupled column per grid point
 
 #ifdef SDSM_PROFILE
@@ -244,12 +244,12 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
         if (tid == 0) { CandState s = {}; s.status = cd.N <= 0 ? ST_ERROR : ST_UNSUPPORTED; *st = s; }
         return;
     }
-    for (int i = tid; i < (T::LABELS + 1) / 32; i += SDSM_WG) fpbits[i] = 0;
-    for (int i = tid; i < T::DIM / 32; i += SDSM_WG) { rowbits[i] = 0; colbits[i] = 0; }
+    for (int i = tid; i < (T::LABELS + 1) / 32; i += T::WG) fpbits[i] = 0;
+    for (int i = tid; i < T::DIM / 32; i += T::WG) { rowbits[i] = 0; colbits[i] = 0; }
     if (tid < 4) mom[tid] = 0;
     if (tid == 0) { sh_M = 0; sh_npos = 0; sh_nneg = 0; sh_err = 0; sh_yhi = 0; }
     __syncthreads();
-    for (int i = tid; i < cd.fp_len; i += SDSM_WG) {
+    for (int i = tid; i < cd.fp_len; i += T::WG) {
         int l = P.fp_labels[cd.fp_off + i];
         if (l >= 1 && l <= T::LABELS) atomicOr(&fpbits[l >> 5], 1u << (l & 31));
     }
@@ -260,13 +260,13 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     int running = 0;
     unsigned long long m_r = 0, m_c = 0, m_rr = 0, m_cc = 0;
     int npos = 0, nneg = 0, yhi = 0;                      // yhi: high word of the largest |y| (non-negative doubles order like their bits)
-    for (int base = 0; base < area; base += 4 * SDSM_WG) {      // four chunks of 256 pixels per pair of barriers (block_excl_count4)
+    for (int base = 0; base < area; base += 4 * T::WG) {      // four chunks of 256 pixels per pair of barriers (block_excl_count4)
         bool flag[4];
         int rr[4], cc4[4];
         double yv4[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int i = base + k * SDSM_WG + tid;
+            const int i = base + k * T::WG + tid;
             flag[k] = false; rr[k] = 0; cc4[k] = 0; yv4[k] = 0;
             if (i < area) {
                 const int r = i / cd.w, c = i - r * cd.w;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
             }
         }
         int total, pos4[4];
-        block_excl_count4(flag, scr32x4, pos4, &total);
+        block_excl_count4<T::WG / 64>(flag, scr32x4, pos4, &total);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (flag[k]) {
@@ -314,13 +314,13 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
 
     SETUP_T(0);
     // ---- 2. compressed coordinates: delete empty rows / columns (dsm.py:185-186) ---------------
-    for (int r = tid; r < cd.h; r += SDSM_WG) {
+    for (int r = tid; r < cd.h; r += T::WG) {
         int cnt = 0;
         for (int wd = 0; wd < (r >> 5); wd++) cnt += __popc(rowbits[wd]);
         cnt += __popc(rowbits[r >> 5] & ((1u << (r & 31)) - 1u));
         rowrank[r] = (uint16_t)cnt;
     }
-    for (int c = tid; c < cd.w; c += SDSM_WG) {
+    for (int c = tid; c < cd.w; c += T::WG) {
         int cnt = 0;
         for (int wd = 0; wd < (c >> 5); wd++) cnt += __popc(colbits[wd]);
         cnt += __popc(colbits[c >> 5] & ((1u << (c & 31)) - 1u));
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
 
     const int S = P.subsample, R = P.R;
     const bool null_matrix = P.no_deform || hc <= P.k / 2 || wc <= P.k / 2;               // dsm.py:187,225
-    for (int i = tid; i < cd.N; i += SDSM_WG) {
+    for (int i = tid; i < cd.N; i += T::WG) {
         uint32_t rc = P.tmp_rc[cd.crop_off + i];
         int r = (int)(rc >> 16) - cd.r0, c = (int)(rc & 0xffffu) - cd.c0;
         uint32_t key = ((uint32_t)rowrank[r] << 16) | (uint32_t)colrank[c];
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
 
     SETUP_T(1);
     // ---- 3. greedy completion of the grid (dsm.py:169-181) --------------------------------------
-    for (int i = tid; i < cd.N; i += SDSM_WG) {
+    for (int i = tid; i < cd.N; i += T::WG) {
         uint32_t key = P.crop_cc[cd.crop_off + i];
         int r = key >> 16, c = key & 0xffffu;
         uint32_t d = 0xffffffffu;                       // distance_transform_bf without any grid point
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     // smallest distance >= subsample; ties -> first pixel in raster order of the compressed mask.  ONE pass over the pixels per
     // added grid point: the pass that lowers the distances to the new point also finds the next candidate.
     unsigned long long best = ~0ull;
-    for (int i = tid; i < cd.N; i += SDSM_WG) {
+    for (int i = tid; i < cd.N; i += T::WG) {
         uint32_t d = P.dist[cd.crop_off + i];
         if (d >= (uint32_t)S) {
             unsigned long long key = ((unsigned long long)d << 32) | P.crop_cc[cd.crop_off + i];
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
         }
     }
     for (;;) {
-        best = block_min_u64(best, scr64);
+        best = block_min_u64<T::WG / 64>(best, scr64);
         if (best == ~0ull) break;
         if (M >= cap) { unsupported = true; break; }
         uint32_t nk = (uint32_t)(best & 0xffffffffull);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
         M++;
         int nr = nk >> 16, nc = nk & 0xffffu;
         best = ~0ull;
-        for (int i = tid; i < cd.N; i += SDSM_WG) {
+        for (int i = tid; i < cd.N; i += T::WG) {
             const uint32_t key = P.crop_cc[cd.crop_off + i];
             const uint32_t t = (uint32_t)cheb(key >> 16, key & 0xffffu, nr, nc);
             uint32_t d = P.dist[cd.crop_off + i];
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     if (unsupported) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
     __syncthreads();
     if (6 + M > SDSM_MAX_N_SOLVE) {                      // the solve kernel only computes the elliptical model (flagged unsupported)
-        for (int i = tid; i < cd.N; i += SDSM_WG) {
+        for (int i = tid; i < cd.N; i += T::WG) {
             P.ell_meta[cd.crop_off + i] = 0;
             P.crop_y[cd.crop_off + i] = P.tmp_y[cd.crop_off + i];
             P.crop_rc[cd.crop_off + i] = P.tmp_rc[cd.crop_off + i];
@@ -418,19 +418,19 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
 
     SETUP_T(2);
     // ---- 4. columns of G~ = grid points in raster order (np.nonzero(col_mask), dsm.py:159) ------
-    for (int j = tid; j < M; j += SDSM_WG) {
+    for (int j = tid; j < M; j += T::WG) {
         uint32_t key = gridkeys[j];
         int rank = 0;
         for (int q = 0; q < M; q++) rank += gridkeys[q] < key;
         P.grid_rc[cd.xi_off + rank] = key;
     }
     __syncthreads();
-    for (int j = tid; j < M; j += SDSM_WG) gridkeys[j] = P.grid_rc[cd.xi_off + j];
+    for (int j = tid; j < M; j += T::WG) gridkeys[j] = P.grid_rc[cd.xi_off + j];
     __syncthreads();
     // first grid point of every compressed row (the row / column rank tables are no longer needed: reuse rowrank): a pixel
     // only looks at the grid points of the rows within R of its own
     uint16_t *growstart = rowrank;
-    for (int r = tid; r < hc && r < T::DIM; r += SDSM_WG) {
+    for (int r = tid; r < hc && r < T::DIM; r += T::WG) {
         int lo = 0, hi = M;                               // first j with row(j) >= r
         while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(gridkeys[mid] >> 16) < r) lo = mid + 1; else hi = mid; }
         growstart[r] = (uint16_t)lo;
@@ -442,10 +442,10 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     //      G~ row, largest first.  A wavefront of the solve kernel then reads 64 rows of (nearly) the same length and
     //      fetches only the groups that exist (CandState.gcount), instead of every row padded to the longest one. ------
     const int ngmax = P.zcap / 4;                        // P.zcap is a multiple of 4, <= 4 * SDSM_MAX_ELL_GROUPS
-    for (int k = tid; k <= ngmax; k += SDSM_WG) { cls_cnt[k] = 0; cls_run[k] = 0; }
+    for (int k = tid; k <= ngmax; k += T::WG) { cls_cnt[k] = 0; cls_run[k] = 0; }
     __syncthreads();
     int cntmax = 0;
-    for (int q = tid; q < cd.N; q += SDSM_WG) {           // raster order (coherent wavefronts), see rows_of_ranks
+    for (int q = tid; q < cd.N; q += T::WG) {           // raster order (coherent wavefronts), see rows_of_ranks
         const int i = (int)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N);
         uint32_t key = P.crop_cc[cd.crop_off + i];
         const int cr = key >> 16, cc = key & 0xffffu;
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __syncthreads();
     {
         const int lane = tid & 63, wave = tid >> 6;
-        for (int base = 0; base < cd.N; base += SDSM_WG) {
-            for (int e = tid; e < SDSM_WAVES * (ngmax + 1); e += SDSM_WG) wave_cnt[e / (ngmax + 1)][e % (ngmax + 1)] = 0;
+        for (int base = 0; base < cd.N; base += T::WG) {
+            for (int e = tid; e < (T::WG / 64) * (ngmax + 1); e += T::WG) wave_cnt[e / (ngmax + 1)][e % (ngmax + 1)] = 0;
             __syncthreads();
             const int i = base + tid;
             const int k = i < cd.N ? (int)P.dist[cd.crop_off + i] : -1;
@@ -494,27 +494,27 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
                 P.dist[cd.crop_off + i] = (uint32_t)(cls_start[k] + cls_run[k] + before + within);
             }
             __syncthreads();
-            for (int k2 = tid; k2 <= ngmax; k2 += SDSM_WG) {
+            for (int k2 = tid; k2 <= ngmax; k2 += T::WG) {
                 int add = 0;
-                for (int w2 = 0; w2 < SDSM_WAVES; w2++) add += wave_cnt[w2][k2];
+                for (int w2 = 0; w2 < (T::WG / 64); w2++) add += wave_cnt[w2][k2];
                 cls_run[k2] += add;
             }
             __syncthreads();
         }
     }
 
-    for (int j = tid; j < M; j += SDSM_WG) efirst[j] = j;
+    for (int j = tid; j < M; j += T::WG) efirst[j] = j;
     __syncthreads();
 
     SETUP_T(4);
     // group count of the first position of every 64-position chunk (padding target of its rows), for rows_of_ranks
-    for (int t = tid; t * 64 < cd.N; t += SDSM_WG) {
+    for (int t = tid; t * 64 < cd.N; t += T::WG) {
         int kh = 0;
         const int head = t * 64;
         for (int k2 = ngmax; k2 >= 0; k2--) if (cls_cnt[k2] > 0 && head >= cls_start[k2]) kh = k2;
         P.inv[cd.crop_off + t] = (uint32_t)kh;
     }
-    const int zmax = -block_min_i32(-cntmax, scr32);
+    const int zmax = -block_min_i32<T::WG / 64>(-cntmax, scr32);
     s.M = M; s.zmax = zmax; s.hzmax = 0;
     for (int j = 0; j < 8; j++) {                        // positions [0, gcount[j]) have rows of more than 4 j entries
         int acc = 0;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     if (cd.wide_g > 0) {
         // a very large region: its rows are built by the members of its workgroup group (sdsm_k_setup_rows), which also
         // finish the envelope; env_size == -1 marks the state as pending
-        for (int j = tid; j < M; j += SDSM_WG) P.env_fst[cd.xi_off + j] = j;
+        for (int j = tid; j < M; j += T::WG) P.env_fst[cd.xi_off + j] = j;
         s.env_size = -1; s.status = ST_OK;
         if (tid == 0) *st = s;
         SETUP_T(5);
@@ -539,15 +539,15 @@ __global__ __launch_bounds__(SDSM_WG, T::WPE) void sdsm_k_setup(BatchParams P)
     const float *psf_lds = nullptr;
     if (P.k * P.k <= T::PSFW) {                     // the footprint bitset is no longer needed
         float *pl = reinterpret_cast<float *>(fp_or_psf);
-        for (int e = tid; e < P.k * P.k; e += SDSM_WG) pl[e] = P.psf[e];
+        for (int e = tid; e < P.k * P.k; e += T::WG) pl[e] = P.psf[e];
         psf_lds = pl;
         __syncthreads();
     }
     bool bad = false;
     int hzmax = 0;
-    rows_of_ranks(P, cd, M, R, hc, gridkeys, growstart, psf_lds, efirst, tid, cd.N, SDSM_WG, bad, hzmax);
+    rows_of_ranks(P, cd, M, R, hc, gridkeys, growstart, psf_lds, efirst, tid, cd.N, T::WG, bad, hzmax);
     if (bad) atomicOr(&sh_err, 1);
-    hzmax = -block_min_i32(-hzmax, scr32);
+    hzmax = -block_min_i32<T::WG / 64>(-hzmax, scr32);
     __syncthreads();
     SETUP_T(5);
     // ---- 6. envelope storage of the Hessian ------------------------------------------------------
@@ -626,9 +626,9 @@ extern "C" int sdsm_setup_class(int max_dim, int max_mcap, int max_label, int k)
 
 extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w, int cls)
 {
-    if (cls == 0) hipLaunchKernelGGL(sdsm_k_setup<SetupLimS>, dim3(P.n), dim3(SDSM_WG), 0, stream, P);
-    else if (cls == 1) hipLaunchKernelGGL(sdsm_k_setup<SetupLimM>, dim3(P.n), dim3(SDSM_WG), 0, stream, P);
-    else hipLaunchKernelGGL(sdsm_k_setup<SetupLimL>, dim3(P.n), dim3(SDSM_WG), 0, stream, P);
+    if (cls == 0) hipLaunchKernelGGL(sdsm_k_setup<SetupLimS>, dim3(P.n), dim3(SetupLimS::WG), 0, stream, P);
+    else if (cls == 1) hipLaunchKernelGGL(sdsm_k_setup<SetupLimM>, dim3(P.n), dim3(SetupLimM::WG), 0, stream, P);
+    else hipLaunchKernelGGL(sdsm_k_setup<SetupLimL>, dim3(P.n), dim3(SetupLimL::WG), 0, stream, P);
     if (n_w > 0) {                                       // (candidate | member << 24) of the workgroup groups
         BatchParams Pw = P;
         Pw.order = order_w; Pw.n = n_w;
