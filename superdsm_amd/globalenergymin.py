@@ -16,7 +16,7 @@ import numpy as np
 from .image import Image
 from .maxsetpack import solve_maxsetpack
 from .minsetcover import DEFAULT_GAMMA, DEFAULT_MAX_ITER, MinSetCover
-from .objects import Object, compute_objects, compute_objects_multi
+from .objects import CvxprogError, Object, compute_objects, compute_objects_multi
 from .output import Text, get_output
 from .pipeline import Stage
 
@@ -215,7 +215,12 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         # the atoms and the cluster universes do not depend on each other (globalenergymin.py:192,199 computes them one after the
         # other): ONE batch of the engine -- a batch costs a round trip to the GPU whatever its size.  (With per-candidate log
         # files the two keep their own batches: their logs go to different directories.)
-        solve(atoms + universes, y_img, atoms_map, dsm_cfg, None, ('Computing objects and universe costs', 'Computed objects and universe costs'), out=out)
+        try:
+            solve(atoms + universes, y_img, atoms_map, dsm_cfg, None, ('Computing objects and universe costs', 'Computed objects and universe costs'), out=out)
+        except CvxprogError as error:                       # the index of a failed candidate counts within its own batch (objects.py:309-318)
+            if error.cidx is not None and error.cidx >= len(atoms):
+                error.cidx -= len(atoms)
+            raise
     else:
         solve(atoms, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 1), out=out, shard=shard)
         solve(universes, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 0),
