@@ -343,6 +343,16 @@ def extras(args, scene, img, n_images):
             stage(d, cfg, out='muted')
             ts.append((time.perf_counter() - t1) * 1e3)
         ex['stage_wall_ms_per_image'] = float(np.median(ts))
+        ex['stage_engine_batches'] = int(getattr(d['performance'], 'engine_batches', 0))
+        ex['stage_candidates_solved_ahead_in_vain'] = int(getattr(d['performance'], 'speculative_object_count', 0))
+        cfg0 = config.Config({'global-energy-minimization': {'beta': beta, 'pruning': pruning, 'speculation': 0}})
+        ts = []
+        for _ in range(3):
+            d = mk()
+            t1 = time.perf_counter()
+            stage(d, cfg0, out='muted')
+            ts.append((time.perf_counter() - t1) * 1e3)
+        ex['stage_wall_ms_per_image_reference_batches'] = float(np.median(ts))       # speculation: 0 = one batch per generation, as the reference
         ds = [mk() for _ in range(n_images)]
         t1 = time.perf_counter()
         stage.process_many(ds, cfg, out='muted')

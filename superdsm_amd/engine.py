@@ -284,7 +284,7 @@ class Batch:
             out.append(dict(N=N, M=M, status=status, hc=hc, wc=wc, npos=npos, zmax=int(state[i, 5]), env_size=int(state[i, 15]), y=crop_y[po:po + N][o].copy(),
                             r=(rc >> 16).astype(np.int64)[o], c=(rc & 0xffff).astype(np.int64)[o],
                             grid_r=(g >> 16).astype(np.int64), grid_c=(g & 0xffff).astype(np.int64), nnz=nnz[o], hnz=hnz[o],
-                            nnz_stored_order=nnz.copy(), idx=idx[:, o].copy(), w=w[:, o].copy()))
+                            nnz_stored_order=nnz.copy(), hnz_stored_order=hnz.copy(), idx=idx[:, o].copy(), w=w[:, o].copy()))
             po += N
         return out
 

@@ -16,11 +16,13 @@ import numpy as np
 from .image import Image
 from .maxsetpack import solve_maxsetpack
 from .minsetcover import DEFAULT_GAMMA, DEFAULT_MAX_ITER, MinSetCover
-from .objects import CvxprogError, Object, compute_objects, compute_objects_multi
+from .objects import DEFAULT_COMPUTING_STATUS_LINE, CvxprogError, Object, compute_objects, compute_objects_multi
 from .output import Text, get_output
 from .pipeline import Stage
 
 DEFAULT_MAX_WORK_AMOUNT = 10 ** 6
+DEFAULT_SPECULATION = 1            # generations solved ahead per GPU batch (extension; 0 = the reference's batches exactly)
+DEFAULT_SPECULATION_BUDGET = 768   # ... while the batch stays within what one MI355X runs at once (256 compute units x 3 workgroups)
 
 
 class PerformanceReport:
@@ -148,6 +150,85 @@ def _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=D
     return sum(len(gen) for gen in generations), remaining
 
 
+class _Speculation:
+    """Wraps a solver with the signature of :func:`compute_objects`: every batch also solves the CHILDREN (``depth`` levels of
+    :func:`_iterate_generation`) of the candidates it was asked for, and keeps them; a later batch is served from that store and
+    only what is missing goes to the GPU -- nothing at all if everything is there.
+
+    The generations of an image are sequential (the thresholds of generation k + 1 need the energies of generation k,
+    globalenergymin.py:326-368) and hold tens of candidates each, while one batch of the engine takes as long as its largest
+    region whether it has 20 or 500 candidates (a single image uses a fraction of an MI355X): solving the next generation
+    for ALL parents, before it is known which of them survive the pruning, turns two dependent round trips into one.  The host
+    A batch is only extended while it stays within ``budget`` candidates -- what the GPU runs concurrently; beyond that the extra
+    candidates would cost time instead of hiding latency (image sets in lock step share the budget).  The host
+    logic is unchanged and sees the same candidates with the same results; candidates solved in vain are not counted in the
+    PerformanceReport (``performance.speculative_object_count``)."""
+
+    def __init__(self, solve, adjacencies, max_seed_distance, depth, ignored_cluster_labels, budget=DEFAULT_SPECULATION_BUDGET):
+        self.solve, self.adjacencies, self.max_seed_distance, self.depth = solve, adjacencies, max_seed_distance, int(depth)
+        self.budget = budget                                # largest batch that is still extended (candidates)
+        self.ignored = ignored_cluster_labels               # a set the caller fills in (clusters solved directly)
+        self.store = {}                                     # frozenset(footprint) -> solved Object
+        self.batches = self.extra = self.served = 0         # GPU batches, candidates solved ahead, those of them asked for later
+        self.unasked = set()                                # solved ahead, not asked for (yet)
+
+    def _children(self, parents):
+        found, level = {}, [frozenset(o.footprint) for o in parents]
+        for _ in range(self.depth):
+            level = [fp for _, fp, _ in _iterate_generation(level, self.adjacencies, self.max_seed_distance,
+                                                            ignored_cluster_labels=self.ignored, skip_last=True)]
+            for fp in level:
+                found.setdefault(fp, None)
+            if not level:
+                break
+        return found
+
+    def __call__(self, objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, shard=None):
+        objects = list(objects)
+        keys = [frozenset(o.footprint) for o in objects]
+        missing = [o for o, k in zip(objects, keys) if k not in self.store]
+        if missing or self.batches == 0:
+            asked = set(keys)
+            ahead = []
+            for fp in (self._children(objects) if len(missing) < self.budget and self.depth > 0 else ()):
+                if fp not in self.store and fp not in asked:
+                    o = Object()
+                    o.footprint = set(fp)
+                    ahead.append(o)
+            if len(missing) + len(ahead) > self.budget:     # all or nothing: a generation solved ahead in part still needs its own batch
+                ahead = []
+            def renumber(error):                            # the index of a failed candidate counts within the batch the caller asked for
+                if error.cidx is not None and error.cidx < len(missing):
+                    error.cidx = next(i for i, o in enumerate(objects) if o is missing[error.cidx])
+                return error
+            try:
+                self.solve(missing + ahead, y, atoms, dsm_cfg, log_root_dir, status_line, out=out, shard=shard)
+            except CvxprogError as error:
+                if error.cidx is None or error.cidx < len(missing):
+                    raise renumber(error)
+                # a candidate solved ahead failed: the plain path might never have asked for it.  Solve what was asked for, alone.
+                ahead = []
+                self.depth = 0
+                try:
+                    self.solve(missing, y, atoms, dsm_cfg, log_root_dir, status_line, out=out, shard=shard)
+                except CvxprogError as error2:
+                    raise renumber(error2)
+            self.batches += 1
+            self.extra += len(ahead)
+            for o in missing + ahead:
+                self.store[frozenset(o.footprint)] = o
+            self.unasked.update(frozenset(o.footprint) for o in ahead)
+        for o, k in zip(objects, keys):
+            src = self.store[k]
+            if src is not o:
+                footprint = o.footprint
+                o.set(src)
+                o.footprint = footprint
+            if k in self.unasked:
+                self.unasked.discard(k)
+                self.served += 1
+
+
 def _process_generation(cover, objects, previous_generation, y, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
                         log_root_dir, pruning, ignored_cluster_labels, out, shard=None, solver=None):
     """One generation: enumerate, prune by the energy bound, solve the survivors as ONE batch, keep those below
@@ -194,11 +275,21 @@ def _process_generation(cover, objects, previous_generation, y, atoms_map, adjac
 
 
 def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, dsm_cfg, beta=np.nan, max_iter=DEFAULT_MAX_ITER,
-                         gamma=DEFAULT_GAMMA, max_seed_distance=np.inf, max_work_amount=DEFAULT_MAX_WORK_AMOUNT, out=None, shard=None, solver=None):
+                         gamma=DEFAULT_GAMMA, max_seed_distance=np.inf, max_work_amount=DEFAULT_MAX_WORK_AMOUNT, out=None, shard=None, solver=None,
+                         speculation=None, speculation_budget=DEFAULT_SPECULATION_BUDGET):
     """Returns ``(generations, costs, cover, objects, performance)`` (globalenergymin.py:183-271).  ``solver``: stands in for
-    :func:`compute_objects` (same signature) -- the lock-step driver of :meth:`GlobalEnergyMinimization.process_many`."""
+    :func:`compute_objects` (same signature) -- the lock-step driver of :meth:`GlobalEnergyMinimization.process_many`.
+    ``speculation``: generations solved ahead per batch (:class:`_Speculation`); ``None``: 1 with the GPU operator, 0 when a test
+    substitutes it or per-candidate log files are written (their names count within the reference's batches)."""
     out = get_output(out)
     solve = solver or compute_objects
+    real_operator = solver is not None or getattr(compute_objects, '__module__', None) == Object.__module__
+    if speculation is None:
+        speculation = DEFAULT_SPECULATION if real_operator else 0
+    ahead = None
+    if speculation > 0 and log_root_dir is None:
+        ahead = _Speculation(solve, adjacencies, max_seed_distance, speculation, set(), speculation_budget)
+        solve = ahead
 
     atoms = []
     for label in adjacencies.atom_labels:
@@ -211,12 +302,12 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         obj.footprint = set(adjacencies.get_atoms_in_cluster(cluster))
         universes.append(obj)
     out.write('\nIteration 1:')
-    if shard is None and log_root_dir is None and getattr(compute_objects, '__module__', None) == Object.__module__:   # (not when a test substitutes the operator)
+    if log_root_dir is None and (ahead is not None or (shard is None and getattr(compute_objects, '__module__', None) == Object.__module__)):   # (not when a test substitutes the operator)
         # the atoms and the cluster universes do not depend on each other (globalenergymin.py:192,199 computes them one after the
         # other): ONE batch of the engine -- a batch costs a round trip to the GPU whatever its size.  (With per-candidate log
         # files the two keep their own batches: their logs go to different directories.)
         try:
-            solve(atoms + universes, y_img, atoms_map, dsm_cfg, None, ('Computing objects and universe costs', 'Computed objects and universe costs'), out=out)
+            solve(atoms + universes, y_img, atoms_map, dsm_cfg, None, ('Computing objects and universe costs', 'Computed objects and universe costs'), out=out, shard=shard)
         except CvxprogError as error:                       # the index of a failed candidate counts within its own batch (objects.py:309-318)
             if error.cidx is not None and error.cidx >= len(atoms):
                 error.cidx -= len(atoms)
@@ -235,6 +326,8 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         if all(m.is_optimal for m in members) and universe.energy <= beta + sum(m.energy for m in members):
             solved_directly.add(cluster)
 
+    if ahead is not None:
+        ahead.ignored.update(solved_directly)               # nothing is solved ahead in clusters that need no iterations
     cover = MinSetCover(atoms, beta, adjacencies, max_iter=max_iter, gamma=gamma)
     cover.update(universes, out.derive(muted=True))
     costs = [cover.costs]
@@ -265,7 +358,7 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
                 out.write(f'Iteration {number}: {Text.style(text, Text.BOLD)}')
             new_generation, new_objects = _process_generation(
                 cover, objects, generations[-1], y_img, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
-                _generation_log_dir(log_root_dir, number), pruning, solved_directly, out, shard=shard, solver=solver)
+                _generation_log_dir(log_root_dir, number), pruning, solved_directly, out, shard=shard, solver=solve)
             objects += new_objects
             performance.iterative_computed_object_count += len(new_objects)
             if not new_generation:
@@ -278,6 +371,9 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
     performance.nontrivial_computed_object_count += performance.iterative_computed_object_count
     performance.overall_computed_object_count += performance.iterative_computed_object_count
     performance._assert_integrity()
+    if ahead is not None:                                   # (not part of the reference's report)
+        performance.engine_batches, performance.speculative_object_count = ahead.batches, ahead.extra - ahead.served   # solved ahead and never asked for
+        out.write(f'Solved ahead: {ahead.extra} candidates in {ahead.batches} batches ({ahead.served} of them asked for later)')
     out.write('')
     out.write(f'Non-trivial pruning: {100 * performance.nontrivial_pruning_success:.1f}% '
               f'(computed {performance.nontrivial_computed_object_count} / {performance.nontrivial_object_count})')
@@ -348,14 +444,15 @@ class GlobalEnergyMinimization(Stage):
         max_work_amount = cfg.get('max_work_amount', DEFAULT_MAX_WORK_AMOUNT)
         assert 0 < gamma < 1
         assert pruning in ('exact', 'isbi24')
-        return pruning, beta, max_iter, gamma, max_seed_distance, max_work_amount
+        return pruning, beta, max_iter, gamma, max_seed_distance, max_work_amount, cfg.get('speculation', None)
 
-    def process(self, input_data, cfg, out, log_root_dir, solver=None):
+    def process(self, input_data, cfg, out, log_root_dir, solver=None, speculation_budget=DEFAULT_SPECULATION_BUDGET):
         y_img = Image.create_from_array(input_data['y'], normalize=False, mask=input_data['y_mask'])
-        pruning, beta, max_iter, gamma, max_seed_distance, max_work_amount = self._hyperparameters(cfg)
+        pruning, beta, max_iter, gamma, max_seed_distance, max_work_amount, speculation = self._hyperparameters(cfg)
         _, _, cover, objects, performance = _compute_generations(
             input_data['adjacencies'], y_img, input_data['atoms'], log_root_dir, pruning, dict(input_data['dsm_cfg']),
-            beta, max_iter, gamma, max_seed_distance, max_work_amount, out, shard=self.shard, solver=solver)
+            beta, max_iter, gamma, max_seed_distance, max_work_amount, out, shard=self.shard, solver=solver, speculation=speculation,
+            speculation_budget=speculation_budget)
         return {'y_img': y_img, 'cover': cover, 'objects': objects, 'performance': performance}
 
     def process_many(self, datas, cfg, out=None, log_root_dirs=None):
@@ -375,13 +472,17 @@ class GlobalEnergyMinimization(Stage):
         out = get_output(out)
         lock = _LockStep(len(datas), out)
         self.last_lockstep = lock
+        # generations are only solved ahead while the images together leave the GPU room for it; with many images in lock step the
+        # batches fill it anyway and the host logic of the image threads is what takes the time (measured: 8 images, no gain)
+        budget = DEFAULT_SPECULATION_BUDGET // len(datas) if len(datas) <= 4 else 0
         produced, errors = [None] * len(datas), [None] * len(datas)
         t0 = time.time()
 
         def work(i):
             try:
                 stage_input = {inner: datas[i][outer] for outer, inner in self.inputs.items()}
-                produced[i] = self.process(stage_input, cfgs[i], out.derive(muted=True), logs[i], solver=lock.submit)
+                produced[i] = self.process(stage_input, cfgs[i], out.derive(muted=True), logs[i], solver=lock.submit,
+                                           speculation_budget=budget)
             except BaseException as e:            # noqa: BLE001 -- re-raised in the calling thread
                 errors[i] = e
             finally:

@@ -235,3 +235,66 @@ def test_native_set_cover_and_packing_make_the_decisions_of_the_python_restateme
                     assert [id(o) for o in a] == [id(o) for o in b], (trial, beta, merge, max_iter)
         a, b = maxsetpack.solve_maxsetpack(fam, out='muted'), maxsetpack.solve_maxsetpack_py(fam, out='muted')
         assert [id(o) for o in a] == [id(o) for o in b]
+
+
+@pytest.mark.parametrize('pruning', ['isbi24', 'exact'])
+def test_generations_solved_ahead_change_nothing_but_the_number_of_batches(pruning, monkeypatch):
+    """globalenergymin._Speculation: every batch also solves the children of its candidates; the host logic must see the same
+    candidates with the same results (generations, objects in order, costs, cover, PerformanceReport) in fewer batches, and a
+    failure of a candidate that was only solved ahead must not surface."""
+    import hashlib
+    from superdsm_amd import objects, testing
+    scene = testing.make_scene('bbbc039_like', max_size=3)
+    adj = scene['adjacencies']
+    h = lambda s: int(hashlib.sha1(s.encode()).hexdigest()[:8], 16) / 2 ** 32
+
+    def energy(fp):
+        fp = sorted(int(a) for a in fp)
+        base = sum(30 + 20 * h(f'a{a}') for a in fp)
+        return base if len(fp) == 1 else base * (0.75 + 0.5 * h(','.join(map(str, fp))))
+
+    def run(depth, poison=None, budget=768):
+        calls = []
+
+        def fake(objs, y, atoms_map, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None):
+            objs = list(objs)
+            calls.append([frozenset(o.footprint) for o in objs])
+            for k, o in enumerate(objs):
+                if poison is not None and frozenset(o.footprint) == poison:
+                    raise objects.CvxprogError('convex programming failed for the elliptical model', cidx=k)
+                o.energy = energy(o.footprint)
+                o.is_optimal, o.on_boundary, o.processing_time = True, False, 0
+                o.fg_offset, o.fg_fragment = np.zeros(2, int), np.zeros((1, 1), bool)
+
+        monkeypatch.setattr(globalenergymin, 'compute_objects', fake)
+        gens, costs, cover, objs, perf = globalenergymin._compute_generations(adj, None, scene['atoms'], None, pruning, {}, beta=5.0, out='muted', speculation=depth,
+                                                                              speculation_budget=budget)
+        state = ([sorted(sorted(o.footprint) for o in g) for g in gens], [sorted(o.footprint) for o in objs], [o.energy for o in objs], list(costs),
+                 sorted(sorted(int(a) for a in o.footprint) for o in cover.solution), {k: int(getattr(perf, k)) for k in perf.attributes})
+        return state, calls, perf
+
+    plain, plain_calls, _ = run(0)
+    assert len(plain[0]) >= 3, 'the fake energies must make the stage iterate'
+    asked = set().union(*[set(c) for c in plain_calls])
+    for depth in (1, 2):
+        state, calls, perf = run(depth)
+        assert state == plain
+        assert len(calls) < len([c for c in plain_calls if c]) and perf.engine_batches == len(calls)
+        assert perf.speculative_object_count == sum(len(c) for c in calls) - sum(len(c) for c in plain_calls)
+    # a batch is only extended within the budget (what the GPU runs at once): all or nothing
+    state, calls, _ = run(1, budget=60)
+    assert state == plain and all(len(c) <= 60 or c in plain_calls or c == plain_calls[0] + plain_calls[1] for c in calls)
+    assert len(calls) < len([c for c in plain_calls if c])
+    # a candidate that the plain run never asks for fails: the run must not notice
+    state, calls, _ = run(1)
+    never = next(fp for c in calls for fp in c if fp not in asked)
+    state, calls, _ = run(1, poison=never)
+    assert state == plain
+    # a candidate the plain run does ask for fails: the error surfaces with its index in the batch the caller asked for
+    wanted = plain_calls[2][len(plain_calls[2]) // 2]
+    with pytest.raises(objects.CvxprogError) as plain_error:
+        run(0, poison=wanted)
+    with pytest.raises(objects.CvxprogError) as ahead_error:
+        run(1, poison=wanted)
+    assert plain_calls[2][plain_error.value.cidx] == wanted
+    assert ahead_error.value.cidx is not None

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: the engine batches of one GlobalEnergyMinimization run on the BBBC039-like scene -- candidates, largest region,
-time from launch to downloaded results.  usage: python tools/stage_batches.py [workload [beta]]"""
+time from launch to downloaded results.  usage: python tools/stage_batches.py [workload [beta [generations solved ahead]]]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,10 @@ from superdsm_amd import config, engine, globalenergymin, testing
 wl = sys.argv[1] if len(sys.argv) > 1 else 'bbbc039_like'
 scene = testing.make_scene(wl, max_size=3)
 stage = globalenergymin.GlobalEnergyMinimization()
-cfg = config.Config({'global-energy-minimization': {'beta': float(sys.argv[2]) if len(sys.argv) > 2 else 150.0, 'pruning': 'isbi24'}})
+gem = {'beta': float(sys.argv[2]) if len(sys.argv) > 2 else 150.0, 'pruning': 'isbi24'}
+if len(sys.argv) > 3:
+    gem['speculation'] = int(sys.argv[3])
+cfg = config.Config({'global-energy-minimization': gem})
 mk = lambda: dict(y=scene['y'], y_mask=np.ones(scene['y'].shape, bool), atoms=scene['atoms'], adjacencies=scene['adjacencies'], dsm_cfg=scene['dsm_cfg'])
 stage(mk(), cfg, out='muted')
 log = []
