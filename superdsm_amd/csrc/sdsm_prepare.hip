@@ -195,6 +195,138 @@ __global__ __launch_bounds__(256) void k_gauss_cols(const double *__restrict__ i
     }
 }
 
+// ---- register-tiled versions (the ones that run; the two kernels above remain for filters too long for their LDS tiles) -----
+// A thread computes GT_K consecutive outputs ALONG the filtered axis and keeps the two windows of inputs that tap j needs --
+// x[p - j .. p - j + K - 1] and x[p + j .. p + j + K - 1] -- in registers: going from tap j to tap j - 1 slides each window by
+// one element, i.e. ONE new LDS read per window instead of K (the loop is unrolled by K so that the slide is a renaming of
+// registers, not a copy).  With one output per thread the filters were bound by LDS bandwidth (2 reads of 8 bytes per tap pair
+// and output: 2.8 KB per pixel of the three filters of the preprocessing); now the FP64 pipes are.  Every output is still
+// accumulated in SciPy's order (centre, then the pairs from the outermost inwards), bit for bit as before.
+#define GT_K 8
+struct CombineArgs {               // epilogue of the last pass of the preprocessing (k_combine fused in); off == nullptr: none
+    const double *off, *offc, *tbuf, *scal;
+    const int *any;
+    double sigma2;
+    int use_clip, lower_clip_mean;
+};
+
+__device__ __forceinline__ double clip_on_load(double v, const double *__restrict__ clip_scal)
+{
+    if (!clip_scal) return v;
+    const double hi = clip_scal[2];
+    return v < 0 ? 0 : (v > hi ? hi : v);                                  // g_raw.clip(0, clip_abs), preprocess.py:53
+}
+
+template <class LoadAt>
+__device__ __forceinline__ void taps_sliding(double (&acc)[GT_K], const double *__restrict__ w, int R, LoadAt x /* x(i): input at offset i from the thread's first output, -R <= i <= GT_K - 1 + R */)
+{
+    double U[GT_K], D[GT_K];
+#pragma unroll
+    for (int k = 0; k < GT_K; k++) { acc[k] = x(k) * w[R]; U[k] = x(k - R); D[k] = x(k + R); }
+    // blocks of GT_K taps: the weights of a block (uniform: scalar loads) and the 2 x GT_K elements that enter the windows during
+    // it are requested together at its start, the taps themselves are then arithmetic only
+    for (int j = R; j >= 1; j -= GT_K) {
+        const int nb = j < GT_K ? j : GT_K;                                 // taps of this block: j, j - 1, ..., j - nb + 1
+        double wj[GT_K], NU[GT_K], ND[GT_K];
+#pragma unroll
+        for (int s = 0; s < GT_K; s++) {
+            const int js = j - s > 1 ? j - s : 1;                           // (clamped: the values of taps beyond the block are not used)
+            wj[s] = w[R - js];
+            NU[s] = x(GT_K - js);                                           // windows of tap js - 1: x[k - (js - 1)], x[k + (js - 1)]
+            ND[s] = x(js - 1);
+        }
+#pragma unroll
+        for (int s = 0; s < GT_K; s++) {
+            if (s < nb) {                                                   // (uniform)
+#pragma unroll
+                for (int k = 0; k < GT_K; k++) acc[k] += (U[(k + s) % GT_K] + D[(k - s + GT_K) % GT_K]) * wj[s];
+                U[s % GT_K] = NU[s];
+                D[(GT_K - s - 1) % GT_K] = ND[s];
+            }
+        }
+    }
+}
+
+// axis 0: a workgroup = TX columns x (TY * GT_K) rows (+ halo rows) in LDS; thread = (column, GT_K consecutive rows)
+template <int TX>
+__global__ __launch_bounds__(256) void k_gauss_cols_t(const double *__restrict__ in, int H, int W, const double *__restrict__ w, int R,
+                                                      const double *__restrict__ clip_scal, double *__restrict__ out)
+{
+    constexpr int TY = 256 / TX, TR = TY * GT_K;
+    double *lds = (double *)sdsm_dyn_lds;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int c = blockIdx.x * TX + tx, r0 = blockIdx.y * TR;
+    const int cs = c < W ? c : W - 1;
+    for (int i = ty; i < TR + 2 * R + 1; i += TY) lds[i * TX + tx] = clip_on_load(in[(size_t)reflect_idx(r0 - R + i, H) * W + cs], clip_scal);
+    __syncthreads();
+    const double *ctr = lds + (ty * GT_K + R) * TX + tx;
+    double acc[GT_K];
+    taps_sliding(acc, w, R, [&](int i) { return ctr[i * TX]; });
+    if (c >= W) return;
+#pragma unroll
+    for (int k = 0; k < GT_K; k++) {
+        const int r = r0 + ty * GT_K + k;
+        if (r < H) out[(size_t)r * W + c] = acc[k];
+    }
+}
+
+// axis 1: a workgroup = 8 rows x 256 columns (+ halo columns) in LDS, one double of padding after every 8 (a thread owns 8
+// consecutive columns: the lanes of a wavefront then read 9 doubles apart -- different banks); thread = (row, GT_K consecutive columns)
+#define GR_ROWS 8
+#define GR_COLS (32 * GT_K)
+__global__ __launch_bounds__(256) void k_gauss_rows_t(const double *__restrict__ in, int H, int W, const double *__restrict__ w, int R,
+                                                      double *__restrict__ out, CombineArgs cmb)
+{
+    double *lds = (double *)sdsm_dyn_lds;
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int c0 = blockIdx.x * GR_COLS, r0 = blockIdx.y * GR_ROWS;
+    const int span = GR_COLS + 2 * R + 1, pitch = span + (span >> 3) + 1;
+    for (int rr = 0; rr < GR_ROWS; rr++) {
+        const int r = r0 + rr < H ? r0 + rr : H - 1;
+        const double *row = in + (size_t)r * W;
+        double *dst = lds + rr * pitch;
+        for (int i = tid; i < span; i += 256) dst[i + (i >> 3)] = row[reflect_idx(c0 - R + i, W)];
+    }
+    __syncthreads();
+    const double *line = lds + ty * pitch;
+    const int q0 = tx * GT_K + R;                                           // LDS column of the thread's first output
+    double acc[GT_K];
+    taps_sliding(acc, w, R, [&](int i) { const int q = q0 + i; return line[q + (q >> 3)]; });
+    // results back through the tile (a thread holds 8 consecutive columns: stored directly, the lanes of a wavefront would write
+    // 64 bytes apart), then rows of 256 consecutive columns leave with one lane per column
+    __syncthreads();
+    {
+        double *dst = lds + ty * pitch;
+#pragma unroll
+        for (int k = 0; k < GT_K; k++) { const int q = tx * GT_K + k; dst[q + (q >> 3)] = acc[k]; }
+    }
+    __syncthreads();
+    const int c = c0 + tid;
+    if (c >= W) return;
+    double tmax = 0, mean = 0;
+    if (cmb.off) {
+        tmax = *cmb.any ? cmb.sigma2 : (cmb.sigma2 - 1.0 < 0 ? 0.0 : cmb.sigma2 - 1.0);
+        if (cmb.lower_clip_mean) mean = cmb.scal[0];
+    }
+    for (int rr = 0; rr < GR_ROWS; rr++) {
+        const int r = r0 + rr;
+        if (r >= H) break;
+        const size_t p = (size_t)r * W + c;
+        double v = lds[rr * pitch + tid + (tid >> 3)];
+        if (cmb.off) {                                                      // y = gauss(g, sigma1) - offset_combined (preprocess.py:57-64), as k_combine
+            double comb;
+            if (cmb.use_clip) {
+                double t = cmb.tbuf[p] / tmax;
+                t = t * t;
+                comb = (1 - t) * cmb.offc[p] + t * cmb.off[p];
+            } else comb = cmb.off[p];
+            if (cmb.lower_clip_mean) { if (!(comb > mean)) comb = mean; }
+            v = v - comb;
+        }
+        out[p] = v;
+    }
+}
+
 // y = gauss(g, sigma1) - ((1 - t) * offset_clipped + t * offset_original),  t = (t / tmax)^2   (preprocess.py:57-64)
 __global__ void k_combine(const double *__restrict__ g1, const double *__restrict__ off, const double *__restrict__ offc,
                           const double *__restrict__ tbuf, size_t n, int use_clip, int lower_clip_mean,
@@ -281,26 +413,50 @@ extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w)
     for (int i = 0; i <= 2 * radius; i++) w[i] = w[i] / s;
 }
 
-// axis 0 with weights (d_w0, R0) into tmp, then axis 1 with (d_w1, R1) into out: scipy.ndimage's order of the axes
-static hipError_t separable2d(const double *in, int H, int W, const double *d_w0, int R0, const double *d_w1, int R1, double *tmp, double *out, hipStream_t stream)
+// axis 0 with weights (d_w0, R0) into tmp, then axis 1 with (d_w1, R1) into out: scipy.ndimage's order of the axes.
+// clip_scal != nullptr: the input is clipped to [0, clip_scal[2]] as it is read; cmb: epilogue of the second pass (or none).
+#define GT_LDS_MAX (64 * 1024)          // tiles of the register-tiled kernels: at least two workgroups per compute unit
+static hipError_t separable2d(const double *in, int H, int W, const double *d_w0, int R0, const double *d_w1, int R1, double *tmp, double *out, hipStream_t stream,
+                              const double *clip_scal = nullptr, const CombineArgs *cmb = nullptr)
 {
-    size_t lds_r = (size_t)(256 + 2 * R1) * 8;
-    if (lds_r > 160 * 1024 - 1024) return hipErrorInvalidValue;
     hipError_t e;
-    size_t lds_c = (size_t)(GC_ROWS + 2 * R0) * 32 * 8;
-    if (lds_c <= 160 * 1024 - 1024) {
-        if ((e = hipFuncSetAttribute((const void *)k_gauss_cols<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_gauss_cols<32>, dim3((W + 31) / 32, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w0, R0, tmp);
+    CombineArgs none = {};
+    const size_t lds_c32 = (size_t)(8 * GT_K + 2 * R0 + 1) * 32 * 8, lds_c16 = (size_t)(16 * GT_K + 2 * R0 + 1) * 16 * 8;
+    if (lds_c32 <= GT_LDS_MAX) {
+        if ((e = hipFuncSetAttribute((const void *)k_gauss_cols_t<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c32)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gauss_cols_t<32>, dim3((W + 31) / 32, (H + 8 * GT_K - 1) / (8 * GT_K)), dim3(256), lds_c32, stream, in, H, W, d_w0, R0, clip_scal, tmp);
+    } else if (lds_c16 <= GT_LDS_MAX) {
+        if ((e = hipFuncSetAttribute((const void *)k_gauss_cols_t<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c16)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gauss_cols_t<16>, dim3((W + 15) / 16, (H + 16 * GT_K - 1) / (16 * GT_K)), dim3(256), lds_c16, stream, in, H, W, d_w0, R0, clip_scal, tmp);
     } else {
-        lds_c = (size_t)(GC_ROWS + 2 * R0) * 8 * 8;
-        if (lds_c > 160 * 1024 - 1024) return hipErrorInvalidValue;
-        if ((e = hipFuncSetAttribute((const void *)k_gauss_cols<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_gauss_cols<8>, dim3((W + 7) / 8, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w0, R0, tmp);
+        if (clip_scal) return hipErrorInvalidValue;                         // (callers clip beforehand when the filter is this long)
+        size_t lds_c = (size_t)(GC_ROWS + 2 * R0) * 32 * 8;
+        if (lds_c <= 160 * 1024 - 1024) {
+            if ((e = hipFuncSetAttribute((const void *)k_gauss_cols<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_gauss_cols<32>, dim3((W + 31) / 32, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w0, R0, tmp);
+        } else {
+            lds_c = (size_t)(GC_ROWS + 2 * R0) * 8 * 8;
+            if (lds_c > 160 * 1024 - 1024) return hipErrorInvalidValue;
+            if ((e = hipFuncSetAttribute((const void *)k_gauss_cols<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_gauss_cols<8>, dim3((W + 7) / 8, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w0, R0, tmp);
+        }
     }
-    if ((e = hipFuncSetAttribute((const void *)k_gauss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gauss_rows, dim3((W + 255) / 256, H), dim3(256), lds_r, stream, (const double *)tmp, H, W, d_w1, R1, out);
+    const int span = GR_COLS + 2 * R1 + 1;
+    const size_t lds_rt = (size_t)GR_ROWS * (span + (span >> 3) + 1) * 8;
+    if (lds_rt <= GT_LDS_MAX) {
+        if ((e = hipFuncSetAttribute((const void *)k_gauss_rows_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gauss_rows_t, dim3((W + GR_COLS - 1) / GR_COLS, (H + GR_ROWS - 1) / GR_ROWS), dim3(256), lds_rt, stream, (const double *)tmp, H, W, d_w1, R1, out,
+                           cmb ? *cmb : none);
+    } else {
+        if (cmb) return hipErrorInvalidValue;
+        const size_t lds_r = (size_t)(256 + 2 * R1) * 8;
+        if (lds_r > 160 * 1024 - 1024) return hipErrorInvalidValue;
+        if ((e = hipFuncSetAttribute((const void *)k_gauss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gauss_rows, dim3((W + 255) / 256, H), dim3(256), lds_r, stream, (const double *)tmp, H, W, d_w1, R1, out);
+    }
     return hipGetLastError();
 }
+static bool tiled_fits(int R) { const int span = GR_COLS + 2 * R + 1; return (size_t)(16 * GT_K + 2 * R + 1) * 16 * 8 <= GT_LDS_MAX && (size_t)GR_ROWS * (span + (span >> 3) + 1) * 8 <= GT_LDS_MAX; }
 
 static hipError_t gauss2d(const double *in, int H, int W, const double *d_w, int R, double *tmp, double *out, hipStream_t stream)
 {
@@ -340,17 +496,25 @@ extern "C" hipError_t sdsm_preprocess_impl(const double *d_g, int H, int W, doub
         hipLaunchKernelGGL(k_partial, dim3(npart), b, 0, stream, d_g, n, 0, (const double *)scal, partial);
         hipLaunchKernelGGL(k_final, dim3(1), b, 0, stream, (const double *)partial, npart, (double)n, 0, offset_clip, scal);
     }
+    const bool fused = tiled_fits(R1) && tiled_fits(R2);       // clip on load and the combination as the epilogue of the last pass
     if (use_clip) {
         hipLaunchKernelGGL(k_partial, dim3(npart), b, 0, stream, d_g, n, 1, (const double *)scal, partial);
         hipLaunchKernelGGL(k_final, dim3(1), b, 0, stream, (const double *)partial, npart, (double)n, 1, offset_clip, scal);
-        hipLaunchKernelGGL(k_clip, g1, b, 0, stream, d_g, n, (const double *)scal, tmpB);
-        e = gauss2d(tmpB, H, W, w2, R2, tmpA, offc, stream);                                 // offset_clipped (:53)
+        if (fused) e = separable2d(d_g, H, W, w2, R2, w2, R2, tmpA, offc, stream, scal);      // offset_clipped (:53), g clipped as it is read
+        else {
+            hipLaunchKernelGGL(k_clip, g1, b, 0, stream, d_g, n, (const double *)scal, tmpB);
+            e = gauss2d(tmpB, H, W, w2, R2, tmpA, offc, stream);
+        }
         if (e != hipSuccess) return e;
         int radius = (int)ceil(sigma2);
         hipLaunchKernelGGL(k_target, g1, b, 0, stream, d_g, n, 1, (const double *)scal, target, any);
         hipLaunchKernelGGL(k_hdist, g2, b, 0, stream, (const uint8_t *)target, H, W, radius, hd);
         hipLaunchKernelGGL(k_vdist, g2, b, 0, stream, (const uint16_t *)hd, H, W, radius, (const int *)any, 0.0,
                            (const uint8_t *)nullptr, (uint8_t *)nullptr, sigma2, tmpB);      // t = max(sigma2 - d, 0)
+    }
+    if (fused) {
+        CombineArgs cmb = {off, offc, tmpB, scal, any, sigma2, use_clip, lower_clip_mean};
+        return separable2d(d_g, H, W, w1, R1, w1, R1, tmpA, d_y, stream, nullptr, &cmb);     // gauss(g, sigma1) - offset_combined (:64)
     }
     // denoised image into tmpA via d_y as the intermediate
     e = gauss2d(d_g, H, W, w1, R1, d_y, tmpA, stream);                                       // gauss(g, sigma1) (:64)

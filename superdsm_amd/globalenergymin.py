@@ -21,7 +21,7 @@ from .output import Text, get_output
 from .pipeline import Stage
 
 DEFAULT_MAX_WORK_AMOUNT = 10 ** 6
-DEFAULT_SPECULATION = 1            # generations solved ahead per GPU batch (extension; 0 = the reference's batches exactly)
+DEFAULT_SPECULATION = 2            # generations solved ahead per GPU batch (extension; 0 = the reference's batches exactly)
 DEFAULT_SPECULATION_BUDGET = 768   # ... while the batch stays within what one MI355X runs at once (256 compute units x 3 workgroups)
 
 

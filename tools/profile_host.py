@@ -28,6 +28,9 @@ def prof(fn, n=25):
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(n)
     print(s.getvalue()[:6000])
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(n)
+    print(s.getvalue()[:6000])
 
 
 for rep in range(3):
