@@ -374,7 +374,14 @@ def extras(args, scene, img, n_images):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t1) / reps * 1e3
         px = shape[0] * shape[1]
-        pre[f'{shape[0]}x{shape[1]}'] = dict(ms=ms, algorithmic_GBps=16 * px / (ms * 1e-3) / 1e9, frac_of_8TBps=16 * px / (ms * 1e-3) / 8e12)
+        # which bound: the separable filters are SciPy's sums bit for bit (unfused multiply and add, centre + R symmetric pairs per axis): 3 R + 1 FP64
+        # vector instructions per pixel, axis and filter -- three filters (sigma2 twice, sigma1 once).  The FP64 vector pipes issue 78.6 / 2 = 39.3 T
+        # of those per second (the peak counts a fused multiply-add as two); that bound is far above the 16 B / pixel HBM figure
+        r1, r2 = int(4 * np.sqrt(2) + 0.5), int(4 * sigma2 + 0.5)
+        ops = 2 * 2 * (3 * r2 + 1) + 2 * (3 * r1 + 1)
+        pre[f'{shape[0]}x{shape[1]}'] = dict(ms=ms, sigma2=sigma2, algorithmic_GBps=16 * px / (ms * 1e-3) / 1e9, frac_of_8TBps=16 * px / (ms * 1e-3) / 8e12,
+                                             fp64_vector_instructions_per_pixel=ops, frac_of_fp64_vector_issue_39_3T=ops * px / (ms * 1e-3) / 39.3e12,
+                                             bound='fp64 vector issue (unfused SciPy-order sums), not HBM')
     ex['preprocess'] = pre
     return ex
 

@@ -71,6 +71,100 @@ __global__ void k_vdist(const uint16_t *__restrict__ hd, int H, int W, int radiu
     }
 }
 
+// ---- the same two passes for radius <= 63, the ones that normally run -------------------------------------------------
+// Row pass with the target test fused in (k_target + k_hdist): a wavefront turns the target flags of 64 consecutive columns into
+// ONE 64-bit word (ballot); a workgroup holds the words of its 256 columns and of 64 columns on either side in LDS, and the
+// distance of a column to the nearest target of its row is a count of leading / trailing zeros of two shifted words -- no loop
+// over the radius, no per-pixel byte reads.
+// mode 0: target = src > 0; mode 1: target = src > scal[2] (see k_target).
+__global__ __launch_bounds__(256) void k_hdist_bits(const double *__restrict__ src, int H, int W, int mode, const double *__restrict__ scal,
+                                                    int radius, uint16_t *__restrict__ hd, int *__restrict__ any)
+{
+    __shared__ unsigned long long words[6];                                // columns c0 - 64 .. c0 + 319
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.y, c0 = blockIdx.x * 256;
+    const double thr = mode == 0 ? 0.0 : scal[2];
+    const double *row = src + (size_t)r * W;
+    const int c = c0 + tid;
+    const bool t = c < W && row[c] > thr;
+    const unsigned long long own = __ballot(t);
+    if (lane == 0) words[1 + wave] = own;
+    if (wave < 2) {                                                         // the halo words: wave 0 the left one, wave 1 the right one
+        const int ch = wave == 0 ? c0 - 64 + lane : c0 + 256 + lane;
+        const unsigned long long hw = __ballot(ch >= 0 && ch < W && row[ch] > thr);
+        if (lane == 0) words[wave == 0 ? 0 : 5] = hw;
+    }
+    if (__syncthreads_or(t) && tid == 0) *any = 1;                         // (every writer stores the same value)
+    if (c >= W) return;
+    const unsigned long long w0 = words[wave], w1 = words[1 + wave], w2 = words[2 + wave];
+    // bit 63 of L = column c, bit 62 = column c - 1, ...; bit 0 of Rt = column c, bit 1 = column c + 1, ...
+    const unsigned long long L = (w1 << (63 - lane)) | (lane == 63 ? 0ull : w0 >> (lane + 1));
+    const unsigned long long Rt = (w1 >> lane) | (lane == 0 ? 0ull : w2 << (64 - lane));
+    const int dl = L ? __clzll((long long)L) : 64 + 64, dr = Rt ? __ffsll((long long)Rt) - 1 : 64 + 64;
+    int d = dl < dr ? dl : dr;
+    d = d > radius ? radius + 1 : d;
+    hd[(size_t)r * W + c] = (uint16_t)d;
+}
+
+// Column pass (k_vdist) on a tile of 64 columns x 64 rows with its halo rows of horizontal distances staged in LDS.
+#define VT_ROWS 64
+__global__ __launch_bounds__(256) void k_vdist_t(const uint16_t *__restrict__ hd, int H, int W, int radius, const int *__restrict__ any,
+                                                 double m2, const uint8_t *__restrict__ y_mask, uint8_t *__restrict__ out_valid,
+                                                 double sigma2, double *__restrict__ out_t)
+{
+    uint16_t *tile = (uint16_t *)sdsm_dyn_lds;                             // (VT_ROWS + 2 radius) x 64
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int c = blockIdx.x * 64 + tx, r0 = blockIdx.y * VT_ROWS;
+    const int cs = c < W ? c : W - 1;
+    const int rows = VT_ROWS + 2 * radius;
+    for (int i = ty; i < rows; i += 4) {
+        const int rr = r0 - radius + i;
+        tile[i * 64 + tx] = rr >= 0 && rr < H ? hd[(size_t)rr * W + cs] : (uint16_t)(radius + 1);     // outside the image: no target
+    }
+    __syncthreads();
+    if (c >= W) return;
+    const bool has_any = *any != 0;
+    for (int k = 0; k < VT_ROWS / 4; k++) {
+        const int rl = ty + 4 * k, r = r0 + rl;
+        if (r >= H) break;
+        long long best = -1;
+        if (!has_any) best = (long long)(r + 1) * (r + 1) + (long long)c * c;   // SciPy's behaviour without any background pixel
+        else {
+            int b = 0x7fffffff;
+            for (int i = 0; i <= 2 * radius; i++) {                         // tile row rl + i is image row r - radius + i
+                const int h = tile[(rl + i) * 64 + tx];
+                const int dr = i - radius;
+                const int d2 = dr * dr + h * h;
+                b = h <= radius && d2 < b ? d2 : b;
+            }
+            if (b != 0x7fffffff) best = b;
+        }
+        const size_t p = (size_t)r * W + c;
+        if (out_valid) out_valid[p] = (best >= 0 && (double)best <= m2) && (y_mask ? y_mask[p] != 0 : true);
+        if (out_t) {
+            double t = best < 0 ? 0.0 : sigma2 - sqrt((double)best);
+            out_t[p] = t < 0 ? 0.0 : t;
+        }
+    }
+}
+
+// target test + the two distance passes; radius <= 63 (a column sees 63 neighbours on either side in two shifted words) runs the bit / tile kernels
+static void launch_bounded_edt(const double *src, int H, int W, int mode, const double *scal, int radius, uint8_t *target, uint16_t *hd, int *any,
+                               double m2, const uint8_t *y_mask, uint8_t *out_valid, double sigma2, double *out_t, hipStream_t stream)
+{
+    const size_t n = (size_t)H * W;
+    dim3 b(256), g2((W + 255) / 256, H);
+    if (radius <= 63) {
+        hipLaunchKernelGGL(k_hdist_bits, g2, b, 0, stream, src, H, W, mode, scal, radius, hd, any);
+        hipLaunchKernelGGL(k_vdist_t, dim3((W + 63) / 64, (H + VT_ROWS - 1) / VT_ROWS), b, (size_t)(VT_ROWS + 2 * radius) * 64 * 2, stream,
+                           (const uint16_t *)hd, H, W, radius, (const int *)any, m2, y_mask, out_valid, sigma2, out_t);
+    } else {
+        hipLaunchKernelGGL(k_target, dim3((n + 255) / 256), b, 0, stream, src, n, mode, scal, target, any);
+        hipLaunchKernelGGL(k_hdist, g2, b, 0, stream, (const uint8_t *)target, H, W, radius, hd);
+        hipLaunchKernelGGL(k_vdist, g2, b, 0, stream, (const uint16_t *)hd, H, W, radius, (const int *)any, m2, y_mask, out_valid, sigma2, out_t);
+    }
+}
+
 __global__ void k_stats_init(int32_t *stats, int n_atoms)
 {
     int l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,6 +241,7 @@ __global__ void k_clip(const double *__restrict__ g, size_t n, const double *__r
 // ---- separable Gaussian, reflect boundary, SciPy's symmetric association order -----------------------
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
+    if ((unsigned)i < (unsigned)n) return i;                 // inside the image: no integer division (only tiles at the border pay for it)
     int p = 2 * n;
     int m = i % p;
     if (m < 0) m += p;
@@ -370,9 +465,7 @@ extern "C" hipError_t sdsm_image_prepare_impl(const double *d_y, const uint8_t *
     int radius = (int)ceil(margin);
     if (radius < 0) radius = 0;
     dim3 b(256), g2((W + 255) / 256, H);
-    hipLaunchKernelGGL(k_target, dim3((n + 255) / 256), b, 0, stream, d_y, n, 0, (const double *)nullptr, target, any);
-    hipLaunchKernelGGL(k_hdist, g2, b, 0, stream, target, H, W, radius, hd);
-    hipLaunchKernelGGL(k_vdist, g2, b, 0, stream, hd, H, W, radius, any, margin * margin, d_y_mask, d_valid, 0.0, (double *)nullptr);
+    launch_bounded_edt(d_y, H, W, 0, nullptr, radius, target, hd, any, margin * margin, d_y_mask, d_valid, 0.0, nullptr, stream);
     hipLaunchKernelGGL(k_stats_init, dim3((n_atoms + 256) / 256), b, 0, stream, d_atom_stats, n_atoms);
     hipLaunchKernelGGL(k_stats, g2, b, 0, stream, d_atoms, d_valid, H, W, n_atoms, d_atom_stats);
     return hipGetLastError();
@@ -413,6 +506,25 @@ extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w)
     for (int i = 0; i <= 2 * radius; i++) w[i] = w[i] / s;
 }
 
+// hipFuncSetAttribute costs microseconds per call: the dynamic LDS limit of a kernel is raised only when a launch needs more than before
+static hipError_t need_lds(const void *fn, size_t bytes)
+{
+    struct Seen { const void *fn; int dev; size_t bytes; };
+    static thread_local Seen seen[32];
+    static thread_local int nseen = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    for (int i = 0; i < nseen; i++) if (seen[i].fn == fn && seen[i].dev == dev) {
+        if (seen[i].bytes >= bytes) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) seen[i].bytes = bytes;
+        return e;
+    }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && nseen < 32 && dev >= 0) { seen[nseen].fn = fn; seen[nseen].dev = dev; seen[nseen].bytes = bytes; nseen++; }
+    return e;
+}
+
 // axis 0 with weights (d_w0, R0) into tmp, then axis 1 with (d_w1, R1) into out: scipy.ndimage's order of the axes.
 // clip_scal != nullptr: the input is clipped to [0, clip_scal[2]] as it is read; cmb: epilogue of the second pass (or none).
 #define GT_LDS_MAX (64 * 1024)          // tiles of the register-tiled kernels: at least two workgroups per compute unit
@@ -423,35 +535,35 @@ static hipError_t separable2d(const double *in, int H, int W, const double *d_w0
     CombineArgs none = {};
     const size_t lds_c32 = (size_t)(8 * GT_K + 2 * R0 + 1) * 32 * 8, lds_c16 = (size_t)(16 * GT_K + 2 * R0 + 1) * 16 * 8;
     if (lds_c32 <= GT_LDS_MAX) {
-        if ((e = hipFuncSetAttribute((const void *)k_gauss_cols_t<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c32)) != hipSuccess) return e;
+        if ((e = need_lds((const void *)k_gauss_cols_t<32>, lds_c32)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_gauss_cols_t<32>, dim3((W + 31) / 32, (H + 8 * GT_K - 1) / (8 * GT_K)), dim3(256), lds_c32, stream, in, H, W, d_w0, R0, clip_scal, tmp);
     } else if (lds_c16 <= GT_LDS_MAX) {
-        if ((e = hipFuncSetAttribute((const void *)k_gauss_cols_t<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c16)) != hipSuccess) return e;
+        if ((e = need_lds((const void *)k_gauss_cols_t<16>, lds_c16)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_gauss_cols_t<16>, dim3((W + 15) / 16, (H + 16 * GT_K - 1) / (16 * GT_K)), dim3(256), lds_c16, stream, in, H, W, d_w0, R0, clip_scal, tmp);
     } else {
         if (clip_scal) return hipErrorInvalidValue;                         // (callers clip beforehand when the filter is this long)
         size_t lds_c = (size_t)(GC_ROWS + 2 * R0) * 32 * 8;
         if (lds_c <= 160 * 1024 - 1024) {
-            if ((e = hipFuncSetAttribute((const void *)k_gauss_cols<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)) != hipSuccess) return e;
+            if ((e = need_lds((const void *)k_gauss_cols<32>, lds_c)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_gauss_cols<32>, dim3((W + 31) / 32, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w0, R0, tmp);
         } else {
             lds_c = (size_t)(GC_ROWS + 2 * R0) * 8 * 8;
             if (lds_c > 160 * 1024 - 1024) return hipErrorInvalidValue;
-            if ((e = hipFuncSetAttribute((const void *)k_gauss_cols<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)) != hipSuccess) return e;
+            if ((e = need_lds((const void *)k_gauss_cols<8>, lds_c)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_gauss_cols<8>, dim3((W + 7) / 8, (H + GC_ROWS - 1) / GC_ROWS), dim3(256), lds_c, stream, in, H, W, d_w0, R0, tmp);
         }
     }
     const int span = GR_COLS + 2 * R1 + 1;
     const size_t lds_rt = (size_t)GR_ROWS * (span + (span >> 3) + 1) * 8;
     if (lds_rt <= GT_LDS_MAX) {
-        if ((e = hipFuncSetAttribute((const void *)k_gauss_rows_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt)) != hipSuccess) return e;
+        if ((e = need_lds((const void *)k_gauss_rows_t, lds_rt)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_gauss_rows_t, dim3((W + GR_COLS - 1) / GR_COLS, (H + GR_ROWS - 1) / GR_ROWS), dim3(256), lds_rt, stream, (const double *)tmp, H, W, d_w1, R1, out,
                            cmb ? *cmb : none);
     } else {
         if (cmb) return hipErrorInvalidValue;
         const size_t lds_r = (size_t)(256 + 2 * R1) * 8;
         if (lds_r > 160 * 1024 - 1024) return hipErrorInvalidValue;
-        if ((e = hipFuncSetAttribute((const void *)k_gauss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r)) != hipSuccess) return e;
+        if ((e = need_lds((const void *)k_gauss_rows, lds_r)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_gauss_rows, dim3((W + 255) / 256, H), dim3(256), lds_r, stream, (const double *)tmp, H, W, d_w1, R1, out);
     }
     return hipGetLastError();
@@ -507,10 +619,7 @@ extern "C" hipError_t sdsm_preprocess_impl(const double *d_g, int H, int W, doub
         }
         if (e != hipSuccess) return e;
         int radius = (int)ceil(sigma2);
-        hipLaunchKernelGGL(k_target, g1, b, 0, stream, d_g, n, 1, (const double *)scal, target, any);
-        hipLaunchKernelGGL(k_hdist, g2, b, 0, stream, (const uint8_t *)target, H, W, radius, hd);
-        hipLaunchKernelGGL(k_vdist, g2, b, 0, stream, (const uint16_t *)hd, H, W, radius, (const int *)any, 0.0,
-                           (const uint8_t *)nullptr, (uint8_t *)nullptr, sigma2, tmpB);      // t = max(sigma2 - d, 0)
+        launch_bounded_edt(d_g, H, W, 1, scal, radius, target, hd, any, 0.0, nullptr, nullptr, sigma2, tmpB, stream);      // t = max(sigma2 - d, 0)
     }
     if (fused) {
         CombineArgs cmb = {off, offc, tmpB, scal, any, sigma2, use_clip, lower_clip_mean};
