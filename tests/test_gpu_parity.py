@@ -429,6 +429,67 @@ def test_sharder_single_rank_equals_direct_batch(gpu):
             dist.destroy_process_group()
 
 
+def _rccl_one_rank(q, port):
+    """Child process: the collectives of the N-GPU paths on the REAL backend (RCCL, device tensors) with a world of one rank."""
+    import os
+    import traceback
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        import torch
+        import torch.distributed as dist
+        from superdsm_amd import dist as sdist
+        from superdsm_amd import engine, testing
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        scene = testing.make_scene('synthetic256', max_size=2)
+        fps = scene['footprints']
+        img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
+        cfg = {k: v for k, v in scene['dsm_cfg'].items() if k != 'background_margin'}
+        # (1) bench.py --gpus N: barrier, gather of device records + masks to rank 0, max-reduction of the time on the device
+        batch = engine.Batch(img, fps, scene['dsm_cfg'])
+        batch.launch()
+        g = sdist.RecordGather(batch, 1, 0, sizes=[[batch.records_dev.numel(), batch.masks_dev.numel()]])
+        dist.barrier()
+        g.run()
+        torch.cuda.synchronize()
+        rec_bytes, mask_bytes = g.unpack()[0]
+        direct = batch.records()
+        ok1 = bool((rec_bytes[:direct.nbytes] == direct.view('u1').reshape(-1)).all()) and bool((mask_bytes == batch.masks_dev.cpu().numpy()).all())
+        t = torch.tensor([1.5], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # (2) Sharder: device-to-device all-gather of the packed block
+        recs, frags = sdist.Sharder().solve(img, fps, cfg)
+        # (3) image sets: the one gather of per-image results
+        got = sdist.gather_objects([(0, [[1, 2]], 3.5, 7)], dst=0)
+        dist.destroy_process_group()
+        q.put(('ok', ok1, float(t.item()), recs['energy'].tolist(), direct['energy'].tolist(), got))
+    except BaseException:                       # noqa: BLE001 -- reported to the parent
+        q.put(('error', traceback.format_exc()))
+
+
+def test_collectives_of_the_multi_gpu_paths_run_on_rccl_with_one_rank(gpu):
+    """`bench.py --gpus N`, `dist.Sharder` and the image-set gather use the backend "nccl" (= RCCL) with device tensors on a real
+    node; the gloo tests cannot see a mistake in THOSE calls (dtypes, device placement, gather of uint8 blocks).  A world of one
+    rank on the one GPU of the box runs exactly those calls through RCCL, in a child process of its own."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank, args=(q, port))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    assert res[0] == 'ok', res[1]
+    _, ok1, tmax, e_shard, e_direct, got = res
+    assert ok1 and tmax == 1.5
+    np.testing.assert_allclose(e_shard, e_direct, rtol=1e-9)
+    assert got == [[(0, [[1, 2]], 3.5, 7)]]
+
+
 def test_latency_mode_gives_the_same_results(gpu):
     """sdsm_plan_set_latency_mode only changes which workgroup size solves the large regions."""
     from superdsm_amd import engine, testing
