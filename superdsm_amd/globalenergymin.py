@@ -172,15 +172,23 @@ class _Speculation:
         self.batches = self.extra = self.served = 0         # GPU batches, candidates solved ahead, those of them asked for later
         self.unasked = set()                                # solved ahead, not asked for (yet)
 
-    def _children(self, parents):
+    def _children(self, parents, limit):
+        """Footprints of the next ``depth`` generations of ``parents``, level by level; a level that would take the batch beyond
+        ``limit`` candidates is dropped together with the deeper ones (all or nothing per level: a generation solved ahead in part
+        still needs its own batch)."""
         found, level = {}, [frozenset(o.footprint) for o in parents]
         for _ in range(self.depth):
-            level = [fp for _, fp, _ in _iterate_generation(level, self.adjacencies, self.max_seed_distance,
-                                                            ignored_cluster_labels=self.ignored, skip_last=True)]
-            for fp in level:
-                found.setdefault(fp, None)
-            if not level:
+            nxt = []
+            for _, fp, _ in _iterate_generation(level, self.adjacencies, self.max_seed_distance, ignored_cluster_labels=self.ignored, skip_last=True):
+                if fp not in self.store:
+                    nxt.append(fp)
+                    if len(found) + len(nxt) > limit:
+                        return found
+            if not nxt:
                 break
+            for fp in nxt:
+                found.setdefault(fp, None)
+            level = nxt
         return found
 
     def __call__(self, objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, shard=None):
@@ -190,13 +198,11 @@ class _Speculation:
         if missing or self.batches == 0:
             asked = set(keys)
             ahead = []
-            for fp in (self._children(objects) if len(missing) < self.budget and self.depth > 0 else ()):
-                if fp not in self.store and fp not in asked:
+            for fp in (self._children(objects, self.budget - len(missing)) if len(missing) < self.budget and self.depth > 0 else ()):
+                if fp not in asked:
                     o = Object()
                     o.footprint = set(fp)
                     ahead.append(o)
-            if len(missing) + len(ahead) > self.budget:     # all or nothing: a generation solved ahead in part still needs its own batch
-                ahead = []
             def renumber(error):                            # the index of a failed candidate counts within the batch the caller asked for
                 if error.cidx is not None and error.cidx < len(missing):
                     error.cidx = next(i for i, o in enumerate(objects) if o is missing[error.cidx])
