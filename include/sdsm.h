@@ -214,6 +214,16 @@ int sdsm_minsetcover(int n, int words, const uint64_t *footprints, const double 
                      double gamma, int32_t *selected, int32_t *n_selected);
 int sdsm_maxsetpack(int n, int words, const uint64_t *footprints, const double *energies, int32_t *selected, int32_t *n_selected);
 
+/* Host helper (no device access): size of the search space of the stage's iterations, per cluster -- what the reference's
+ * _estimate_progress (superdsm/globalenergymin.py:310-323) enumerates footprint by footprint in Python from the generation of the
+ * atoms on: the number of footprints that growing by one adjacent atom at a time produces (_iterate_generation,
+ * globalenergymin.py:292-307; skip_last: the universe of a cluster is not counted).  Atoms of cluster k: offsets[k] .. offsets[k+1]-1;
+ * adj / compat: per atom, the bit set (local indices within its cluster) of its adjacent atoms / of the atoms within
+ * max_seed_distance of it (NULL: no limit).  counts[k] = -1 for clusters of more than 64 atoms.  Counting stops once the total
+ * exceeds max_amount. */
+int sdsm_count_growth(int n_clusters, const int32_t *offsets, const uint64_t *adj, const uint64_t *compat, int skip_last,
+                      int64_t max_amount, int64_t *counts);
+
 /* Host helper (no device access): the foreground fragments (objects.py:148-174) of a batch out of the downloaded records and
  * bit-packed masks, one byte per pixel: fragment i (fg_h x fg_w, row-major) at out + out_offset[i]; candidates without a
  * foreground get the single byte 0 ([[False]], objects.py:172-174).  Returns the bytes written -- or needed, when out == NULL. */

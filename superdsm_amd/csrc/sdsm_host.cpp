@@ -7,6 +7,7 @@
 // Footprints are bit sets over the atoms of one cluster: `words` uint64 per object.
 #include <algorithm>
 #include <cstdint>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/sdsm.h"
@@ -131,5 +132,46 @@ extern "C" int sdsm_maxsetpack(int n, int words, const uint64_t *footprints, con
     }
     *n_selected = (int32_t)packed.size();
     for (size_t i = 0; i < packed.size(); i++) selected[i] = packed[i];
+    return SDSM_OK;
+}
+
+// Size of the search space of the iterations (globalenergymin.py:292-323, _estimate_progress from the atoms on): for every cluster
+// the number of footprints that growing the single atoms by one adjacent atom at a time produces, generation after generation
+// (de-duplicated within a generation) -- the connected atom subsets of 2 .. n atoms (n - 1 with skip_last: the universe is computed
+// separately) whose atoms are pairwise compatible (seed distance).  Atoms of cluster k are offsets[k] .. offsets[k + 1] - 1; adj /
+// compat hold, per atom, the bit set of its neighbours / of the atoms it may share a footprint with, as LOCAL bit indices of its
+// cluster (compat == NULL: all).  Clusters of more than 64 atoms get -1 (the caller enumerates them itself).  Stops counting once the
+// total exceeds max_amount (the caller raises, as the reference does).
+extern "C" int sdsm_count_growth(int n_clusters, const int32_t *offsets, const uint64_t *adj, const uint64_t *compat, int skip_last,
+                                 int64_t max_amount, int64_t *counts)
+{
+    if (n_clusters < 0 || !offsets || !counts || (n_clusters > 0 && !adj)) return SDSM_ERR_ARGUMENT;
+    int64_t total = 0;
+    for (int k = 0; k < n_clusters; k++) {
+        const int lo = offsets[k], n = offsets[k + 1] - lo;
+        if (n > 64) { counts[k] = -1; continue; }
+        counts[k] = 0;
+        std::vector<uint64_t> current(n);
+        for (int a = 0; a < n; a++) current[a] = 1ull << a;
+        int size = 1;
+        while (!current.empty() && total <= max_amount) {
+            if (skip_last && size + 1 == n) break;                               // no footprint of this generation is grown
+            std::unordered_set<uint64_t> next;
+            for (uint64_t fp : current) {
+                uint64_t nb = 0;
+                for (uint64_t m = fp; m; m &= m - 1) nb |= adj[lo + __builtin_ctzll(m)];
+                nb &= ~fp;
+                for (uint64_t m = nb; m; m &= m - 1) {
+                    const int a = __builtin_ctzll(m);
+                    if (compat && (compat[lo + a] & fp) != fp) continue;
+                    next.insert(fp | (1ull << a));
+                }
+            }
+            counts[k] += (int64_t)next.size();
+            total += (int64_t)next.size();
+            current.assign(next.begin(), next.end());
+            size++;
+        }
+    }
     return SDSM_OK;
 }

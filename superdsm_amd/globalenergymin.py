@@ -90,37 +90,63 @@ def _within_seed_distance(footprint, new_atom, adjacencies, max_seed_distance):
     return all(np.linalg.norm(np.asarray(adjacencies.get_seed(a)) - seed) <= max_seed_distance for a in footprint)
 
 
+def _expand(footprint, adjacencies, max_seed_distance, skip_last):
+    """``(cluster, ((grown footprint, new atom), ...))``: the footprint grown by every adjacent atom within the seed distance."""
+    cluster = adjacencies.get_cluster_label(next(iter(footprint)))
+    if skip_last and len(footprint) + 1 == len(adjacencies.get_atoms_in_cluster(cluster)):
+        return cluster, ()                                  # the universe is computed separately
+    neighbours = set()
+    for atom in footprint:
+        neighbours |= adjacencies[atom] - footprint
+    unbounded = np.isinf(max_seed_distance)
+    return cluster, tuple((frozenset(footprint | {new_atom}), new_atom) for new_atom in neighbours
+                          if unbounded or _within_seed_distance(footprint, new_atom, adjacencies, max_seed_distance))
+
+
 def _iterate_generation(previous_generation, adjacencies, max_seed_distance, get_footprint=lambda item: item,
-                        ignored_cluster_labels=frozenset(), skip_last=False):
+                        ignored_cluster_labels=frozenset(), skip_last=False, memo=None):
     """Yields ``(item, new_footprint, new_atom)``: every footprint of the previous generation grown by one adjacent
-    atom, de-duplicated within the generation (globalenergymin.py:292-307)."""
+    atom, de-duplicated within the generation (globalenergymin.py:292-307).  ``memo``: a dict that keeps the expansions of the
+    footprints across calls (same adjacencies, seed distance and ``skip_last``): the stage enumerates what is left of the search
+    space for its statistics, then the generations themselves, then the candidates to solve ahead -- the same footprints."""
     seen = set()
     for item in previous_generation:
         footprint = get_footprint(item)
-        cluster = adjacencies.get_cluster_label(next(iter(footprint)))
+        if memo is None:
+            cluster, children = _expand(footprint, adjacencies, max_seed_distance, skip_last)
+        else:
+            key = footprint if type(footprint) is frozenset else frozenset(footprint)
+            entry = memo.get(key)
+            if entry is None:
+                entry = memo[key] = _expand(footprint, adjacencies, max_seed_distance, skip_last)
+            cluster, children = entry
         if cluster in ignored_cluster_labels:
             continue
-        if skip_last and len(footprint) + 1 == len(adjacencies.get_atoms_in_cluster(cluster)):
-            continue                                        # the universe is computed separately
-        neighbours = set()
-        for atom in footprint:
-            neighbours |= adjacencies[atom] - footprint
-        for new_atom in neighbours:
-            if not _within_seed_distance(footprint, new_atom, adjacencies, max_seed_distance):
-                continue
-            grown = frozenset(footprint | {new_atom})
+        for grown, new_atom in children:
             if grown not in seen:
                 seen.add(grown)
                 yield item, grown, new_atom
 
 
-def _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amount=DEFAULT_MAX_WORK_AMOUNT, skip_last=False):
-    """Footprints still to be enumerated after the last generation, per cluster (a footprint never leaves its cluster)."""
+def _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amount=DEFAULT_MAX_WORK_AMOUNT, skip_last=False, memo=None):
+    """Footprints still to be enumerated after the last generation, per cluster (a footprint never leaves its cluster).  From the
+    generation of the atoms on (the only way the stage calls it) the counting is native host code (sdsm_count_growth: bit sets per
+    cluster, same numbers -- tested against the enumeration below); clusters of more than 64 atoms are enumerated here."""
     current = [c.footprint for c in generations[-1]]
     remaining = {}
     total = 0
+    if len(generations) == 1 and all(len(fp) == 1 for fp in current):
+        counted = _count_growth_native(adjacencies, {next(iter(fp)) for fp in current}, max_seed_distance, skip_last, max_amount)
+        if counted is not None:
+            counts, current = counted                       # current: the atoms of the clusters that were too large for the bit sets
+            for cl, n in counts.items():
+                if n > 0:
+                    remaining[cl] = n
+                    total += n
+            if total > max_amount:
+                raise ValueError('estimated work amount is too large')
     while current:
-        current = [fp for _, fp, _ in _iterate_generation(current, adjacencies, max_seed_distance, skip_last=skip_last)]
+        current = [fp for _, fp, _ in _iterate_generation(current, adjacencies, max_seed_distance, skip_last=skip_last, memo=memo)]
         for fp in current:
             cl = adjacencies.get_cluster_label(next(iter(fp)))
             remaining[cl] = remaining.get(cl, 0) + 1
@@ -130,8 +156,54 @@ def _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amoun
     return remaining
 
 
+def _count_growth_native(adjacencies, atom_labels, max_seed_distance, skip_last, max_amount):
+    """``({cluster: count}, [footprints of the atoms of clusters left to the caller])`` or None if the native library is missing."""
+    try:
+        from . import _capi
+        L = _capi.lib()
+    except Exception:                                       # noqa: BLE001 -- host logic must work without the library (CPU tests of the logic)
+        return None
+    clusters = [cl for cl in adjacencies.cluster_labels]
+    offsets = np.zeros(len(clusters) + 1, np.int32)
+    adj, compat, members = [], [], []
+    bounded = not np.isinf(max_seed_distance)
+    for k, cl in enumerate(clusters):
+        atoms = [a for a in sorted(adjacencies.get_atoms_in_cluster(cl)) if a in atom_labels]
+        members.append(atoms)
+        offsets[k + 1] = offsets[k] + len(atoms)
+        if len(atoms) > 64:
+            adj.extend([0] * len(atoms))
+            compat.extend([0] * len(atoms))
+            continue
+        bit = {a: i for i, a in enumerate(atoms)}
+        for a in atoms:
+            m = 0
+            for b in adjacencies[a]:
+                if b in bit:
+                    m |= 1 << bit[b]
+            adj.append(m)
+        if bounded:
+            seeds = np.asarray([adjacencies.get_seed(a) for a in atoms], float).reshape(len(atoms), -1)
+            for i in range(len(atoms)):
+                # the reference's test, value by value: np.linalg.norm(seed_a - seed_new) <= max_seed_distance (globalenergymin.py:285-289)
+                m = 0
+                for j in range(len(atoms)):
+                    if np.linalg.norm(seeds[j] - seeds[i]) <= max_seed_distance:
+                        m |= 1 << j
+                compat.append(m)
+    adj_a = np.array(adj, np.uint64) if adj else np.zeros(1, np.uint64)
+    compat_a = np.array(compat, np.uint64) if bounded and compat else None
+    counts = np.zeros(max(1, len(clusters)), np.int64)
+    p = lambda a: a.ctypes.data
+    code = L.sdsm_count_growth(len(clusters), p(offsets), p(adj_a), p(compat_a) if compat_a is not None else None, int(bool(skip_last)),
+                               int(max_amount), p(counts))
+    assert code == 0, 'sdsm_count_growth: bad argument'
+    rest = [frozenset([a]) for k in range(len(clusters)) if counts[k] < 0 for a in members[k]]
+    return {cl: int(counts[k]) for k, cl in enumerate(clusters) if counts[k] >= 0}, rest
+
+
 def _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=DEFAULT_MAX_WORK_AMOUNT,
-                       ignored_cluster_labels=frozenset(), skip_last=False, by_cluster=None):
+                       ignored_cluster_labels=frozenset(), skip_last=False, by_cluster=None, memo=None):
     """``(finished, remaining)`` (globalenergymin.py:310-323).  ``by_cluster``: the result of :func:`_remaining_by_cluster` for the
     same state (one enumeration serves several sets of ignored clusters)."""
     if by_cluster is None:
@@ -139,7 +211,7 @@ def _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=D
         remaining = 0
         while current:
             current = [fp for _, fp, _ in _iterate_generation(current, adjacencies, max_seed_distance,
-                                                              ignored_cluster_labels=ignored_cluster_labels, skip_last=skip_last)]
+                                                              ignored_cluster_labels=ignored_cluster_labels, skip_last=skip_last, memo=memo)]
             remaining += len(current)
             if remaining > max_amount:
                 raise ValueError('estimated work amount is too large')
@@ -164,7 +236,8 @@ class _Speculation:
     logic is unchanged and sees the same candidates with the same results; candidates solved in vain are not counted in the
     PerformanceReport (``performance.speculative_object_count``)."""
 
-    def __init__(self, solve, adjacencies, max_seed_distance, depth, ignored_cluster_labels, budget=DEFAULT_SPECULATION_BUDGET):
+    def __init__(self, solve, adjacencies, max_seed_distance, depth, ignored_cluster_labels, budget=DEFAULT_SPECULATION_BUDGET, memo=None):
+        self.memo = memo
         self.solve, self.adjacencies, self.max_seed_distance, self.depth = solve, adjacencies, max_seed_distance, int(depth)
         self.budget = budget                                # largest batch that is still extended (candidates)
         self.ignored = ignored_cluster_labels               # a set the caller fills in (clusters solved directly)
@@ -179,7 +252,8 @@ class _Speculation:
         found, level = {}, [frozenset(o.footprint) for o in parents]
         for _ in range(self.depth):
             nxt = []
-            for _, fp, _ in _iterate_generation(level, self.adjacencies, self.max_seed_distance, ignored_cluster_labels=self.ignored, skip_last=True):
+            for _, fp, _ in _iterate_generation(level, self.adjacencies, self.max_seed_distance, ignored_cluster_labels=self.ignored, skip_last=True,
+                                                memo=self.memo):
                 if fp not in self.store:
                     nxt.append(fp)
                     if len(found) + len(nxt) > limit:
@@ -236,14 +310,14 @@ class _Speculation:
 
 
 def _process_generation(cover, objects, previous_generation, y, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
-                        log_root_dir, pruning, ignored_cluster_labels, out, shard=None, solver=None):
+                        log_root_dir, pruning, ignored_cluster_labels, out, shard=None, solver=None, memo=None):
     """One generation: enumerate, prune by the energy bound, solve the survivors as ONE batch, keep those below
     their threshold (globalenergymin.py:326-368)."""
     new_objects, thresholds = [], []
     discarded = 0
     last_cluster, cluster_costs = None, None
     for parent, footprint, new_atom in _iterate_generation(previous_generation, adjacencies, max_seed_distance,
-                                                           lambda c: c.footprint, ignored_cluster_labels, skip_last=True):
+                                                           lambda c: c.footprint, ignored_cluster_labels, skip_last=True, memo=memo):
         cluster = adjacencies.get_cluster_label(next(iter(parent.footprint)))
         if cluster != last_cluster:
             last_cluster, cluster_costs = cluster, cover.get_cluster_costs(cluster)
@@ -293,8 +367,9 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
     if speculation is None:
         speculation = DEFAULT_SPECULATION if real_operator else 0
     ahead = None
+    memo = {}                                               # expansions of footprints (skip_last=True), shared by every enumeration below
     if speculation > 0 and log_root_dir is None:
-        ahead = _Speculation(solve, adjacencies, max_seed_distance, speculation, set(), speculation_budget)
+        ahead = _Speculation(solve, adjacencies, max_seed_distance, speculation, set(), speculation_budget, memo)
         solve = ahead
 
     atoms = []
@@ -345,8 +420,8 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
     generations = [atoms]
     objects = atoms + universes
     progress = lambda ignored: _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=max_work_amount,
-                                                  ignored_cluster_labels=ignored, skip_last=True)
-    by_cluster = _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amount=max_work_amount, skip_last=True)
+                                                  ignored_cluster_labels=ignored, skip_last=True, memo=memo)
+    by_cluster = _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amount=max_work_amount, skip_last=True, memo=memo)
     first = lambda ignored: _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=max_work_amount,
                                                ignored_cluster_labels=ignored, skip_last=True, by_cluster=by_cluster)
     performance.nontrivial_object_count = first(trivial)[1]      # (one enumeration for both counts: a footprint stays in its cluster)
@@ -364,7 +439,7 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
                 out.write(f'Iteration {number}: {Text.style(text, Text.BOLD)}')
             new_generation, new_objects = _process_generation(
                 cover, objects, generations[-1], y_img, atoms_map, adjacencies, dsm_cfg, max_seed_distance,
-                _generation_log_dir(log_root_dir, number), pruning, solved_directly, out, shard=shard, solver=solve)
+                _generation_log_dir(log_root_dir, number), pruning, solved_directly, out, shard=shard, solver=solve, memo=memo)
             objects += new_objects
             performance.iterative_computed_object_count += len(new_objects)
             if not new_generation:

@@ -62,16 +62,20 @@ def _solve_once(objects, beta, merge, out):
 def _bitsets(objects):
     """Footprints as bit sets over the atoms that occur: (uint64 array [n, words], words)."""
     index = {}
+    ints = []
     for c in objects:
-        for a in c.footprint:
-            if a not in index:
-                index[a] = len(index)
-    words = max(1, (len(index) + 63) // 64)
-    masks = np.zeros((len(objects), words), np.uint64)
-    for i, c in enumerate(objects):
         m = 0
         for a in c.footprint:
-            m |= 1 << index[a]
+            i = index.get(a)
+            if i is None:
+                i = index[a] = len(index)
+            m |= 1 << i
+        ints.append(m)
+    words = max(1, (len(index) + 63) // 64)
+    if words == 1:
+        return np.array(ints, np.uint64).reshape(len(objects), 1), 1
+    masks = np.zeros((len(objects), words), np.uint64)
+    for i, m in enumerate(ints):
         for w in range(words):
             masks[i, w] = (m >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
     return masks, words
@@ -88,16 +92,18 @@ def solve_minsetcover(objects, beta, merge=True, max_iter=DEFAULT_MAX_ITER, gamm
     from . import _capi
     L = _capi.lib()
     masks, words = _bitsets(objects)
-    energies = np.ascontiguousarray([c.energy for c in objects], np.float64)
+    energies = np.array([c.energy for c in objects], np.float64)
     if not np.isfinite(energies).all():
         return solve_minsetcover_py(objects, beta, merge, max_iter, gamma, out)
-    sel = np.zeros(len(objects), np.int32)
-    nsel = ctypes.c_int32(0)
-    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    code = L.sdsm_minsetcover(len(objects), words, ptr(masks), ptr(energies), float(beta), int(bool(merge)), int(max_iter), float(gamma), ptr(sel), ctypes.byref(nsel))
+    sel = np.zeros(len(objects) + 1, np.int32)              # (the count of selected objects in the last element)
+    ptr = lambda a: a.__array_interface__['data'][0]         # (ctypes' data_as costs microseconds per call; this runs a hundred times per image)
+    code = L.sdsm_minsetcover(len(objects), words, ptr(masks), ptr(energies), float(beta), int(bool(merge)), int(max_iter), float(gamma), ptr(sel),
+                              ptr(sel) + 4 * len(objects))
     assert code == 0, 'sdsm_minsetcover: bad argument'
-    get_output(out).write(f'MINSETCOVER accepted objects: {nsel.value}')
-    return [objects[i] for i in sel[:nsel.value]]
+    nsel = int(sel[-1])
+    if out is not None and out != 'muted' and not getattr(out, 'muted', False):
+        get_output(out).write(f'MINSETCOVER accepted objects: {nsel}')
+    return [objects[i] for i in sel[:nsel].tolist()]
 
 
 def solve_minsetcover_py(objects, beta, merge=True, max_iter=DEFAULT_MAX_ITER, gamma=DEFAULT_GAMMA, out=None):

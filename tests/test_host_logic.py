@@ -298,3 +298,30 @@ def test_generations_solved_ahead_change_nothing_but_the_number_of_batches(pruni
         run(1, poison=wanted)
     assert plain_calls[2][plain_error.value.cidx] == wanted
     assert ahead_error.value.cidx is not None
+
+
+@pytest.mark.parametrize('workload', ['bbbc039_like', 'nih3t3_like', 'synthetic256'])
+def test_native_search_space_count_equals_the_enumeration(workload):
+    """sdsm_count_growth (host C++, bit sets per cluster) against the footprint-by-footprint enumeration of _iterate_generation
+    that the reference's _estimate_progress does: same count per cluster, with and without the universe, for every seed distance."""
+    import unittest.mock as mock
+    from superdsm_amd import objects, testing
+    scene = testing.make_scene(workload, max_size=2)
+    adj = scene['adjacencies']
+    atoms = []
+    for label in adj.atom_labels:
+        o = objects.Object()
+        o.footprint = {label}
+        atoms.append(o)
+    assert globalenergymin._count_growth_native(adj, set(adj.atom_labels), np.inf, True, 10 ** 6) is not None
+    for max_seed_distance in (np.inf, 80.0, 30.0):
+        for skip_last in (True, False):
+            native = globalenergymin._remaining_by_cluster([atoms], adj, max_seed_distance, skip_last=skip_last)
+            with mock.patch.object(globalenergymin, '_count_growth_native', lambda *a, **k: None):
+                enumerated = globalenergymin._remaining_by_cluster([atoms], adj, max_seed_distance, skip_last=skip_last)
+            assert native == enumerated
+    total = sum(globalenergymin._remaining_by_cluster([atoms], adj, np.inf, skip_last=True).values())
+    if total > 1:
+        with pytest.raises(ValueError):
+            globalenergymin._remaining_by_cluster([atoms], adj, np.inf, max_amount=total - 1, skip_last=True)
+        globalenergymin._remaining_by_cluster([atoms], adj, np.inf, max_amount=total, skip_last=True)
