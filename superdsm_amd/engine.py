@@ -71,7 +71,7 @@ class DeviceImage:
         self.atom_stats = np.ascontiguousarray(stats.cpu().numpy())       # host copy used by the planner (synchronises)
 
 
-_PINNED = {}                       # (device type, index) -> (records staging, masks staging): pinned, grown on demand, shared
+_PINNED = {}                       # (device type, index, stream) -> (records staging, masks staging): pinned, grown on demand, shared by the batches of a stream
 _PINNED_LOCK = threading.Lock()
 
 
@@ -193,9 +193,9 @@ class Batch:
     def download(self):
         """Records and bit-packed masks to pinned host staging buffers: two asynchronous copies on the current stream, one
         synchronisation.  Returns (records structured array, masks uint8 array) -- VIEWS of the staging buffers, which are shared
-        by all batches of the device and valid until the next download (copy what must live longer)."""
+        by all batches of the device AND STREAM and valid until the next download on it (copy what must live longer)."""
         dev = self.image.device
-        key = (dev.type, dev.index)
+        key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)     # per stream: image groups in a pipeline download concurrently
         with _PINNED_LOCK:
             cur = _PINNED.get(key)
             need = (self.records_dev.numel(), self.masks_dev.numel())

@@ -7,7 +7,9 @@ Drop-in for the reference stage (superdsm/globalenergymin.py:97-368): same stage
 generation / pruning logic is host-side bookkeeping and is restated here; every ``compute_objects`` call is one GPU
 batch.
 """
+import gc
 import os
+import sys
 import threading
 import time
 
@@ -466,8 +468,8 @@ class _LockStep:
     """Rendezvous of the per-image threads of :meth:`GlobalEnergyMinimization.process_many`: ``submit`` has the signature of
     :func:`compute_objects`; when every thread that is still running has submitted a batch, all of them are solved together."""
 
-    def __init__(self, n, out):
-        self.active, self.out = n, out
+    def __init__(self, n, out, stream=None):
+        self.active, self.out, self.stream = n, out, stream   # stream: the torch stream this group's batches run on (None: the current one)
         self.jobs, self.round, self.error = [], 0, None
         self.cv = threading.Condition()
         self.batches = 0                      # multi-image batches solved (diagnostics / tests)
@@ -495,7 +497,12 @@ class _LockStep:
         try:
             cfg = jobs[0][3]
             assert all(j[3] == cfg for j in jobs), 'the images of one lock-step run share the dsm/* hyper-parameters'
-            compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out)
+            if self.stream is None:
+                compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out)
+            else:
+                import torch
+                with torch.cuda.stream(self.stream):
+                    compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out)
             self.batches += 1
         except BaseException as e:               # noqa: BLE001 -- handed to every waiting thread
             self.error = e
@@ -553,6 +560,9 @@ class GlobalEnergyMinimization(Stage):
         out = get_output(out)
         lock = _LockStep(len(datas), out)
         self.last_lockstep = lock
+        locks, n_groups = [lock], 1
+        # (Measured and dropped: two groups of images on streams of their own, the host logic of one overlapping the batch of the other
+        # -- 13.5 vs 14.2 ms per image for 8 images: a batch of 4 images takes as long as one of 8, both as long as their largest region.)
         # generations are only solved ahead while the images together leave the GPU room for it; with many images in lock step the
         # batches fill it anyway and the host logic of the image threads is what takes the time (measured: 8 images, no gain)
         budget = DEFAULT_SPECULATION_BUDGET // len(datas) if len(datas) <= 4 else 0
@@ -562,18 +572,31 @@ class GlobalEnergyMinimization(Stage):
         def work(i):
             try:
                 stage_input = {inner: datas[i][outer] for outer, inner in self.inputs.items()}
-                produced[i] = self.process(stage_input, cfgs[i], out.derive(muted=True), logs[i], solver=lock.submit,
+                produced[i] = self.process(stage_input, cfgs[i], out.derive(muted=True), logs[i], solver=locks[i % n_groups].submit,
                                            speculation_budget=budget)
             except BaseException as e:            # noqa: BLE001 -- re-raised in the calling thread
                 errors[i] = e
             finally:
-                lock.leave()
+                locks[i % n_groups].leave()
 
-        threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(datas))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        # The image threads hand the interpreter lock to each other at every rendezvous; with CPython's default switch interval (5 ms)
+        # a thread that wakes up may wait that long for the one that is computing -- as long as a whole batch takes on the GPU.
+        # No cyclic garbage collection while the threads run: a full collection of a process that has PyTorch loaded takes tens of
+        # milliseconds and stops all of them (measured: every other run of an 8-image set 6 ms per image slower).
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(interval, 2e-4))
+        collecting = gc.isenabled()
+        gc.disable()
+        try:
+            threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(datas))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            sys.setswitchinterval(interval)
+            if collecting:
+                gc.enable()
         for e in errors:
             if e is not None:
                 raise e
