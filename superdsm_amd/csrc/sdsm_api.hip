@@ -117,7 +117,7 @@ struct PlanImage { int H, W, n_atoms; };
 // Side streams / fork-join events of the solve classes.  A plan borrows a set at its first launch and gives it back when it is
 // destroyed: creating and destroying HIP streams costs milliseconds (hipStreamDestroy synchronises), a reference-style caller
 // builds a plan per batch.  A set carries no state between users (events are recorded before they are waited for).
-struct SideSet { hipStream_t side[2]; hipEvent_t fj[3]; int device; };
+struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; int device; };
 struct sdsm_plan {
     int n = 0;
     std::vector<PlanImage> images;             // one entry for sdsm_plan_create, several for sdsm_plan_create_multi
@@ -164,8 +164,8 @@ static hipError_t acquire_sides(const sdsm_plan *p)
     }
     SideSet *s = new SideSet();
     s->device = dev;
-    for (int i = 0; i < 2; i++) if ((e = hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking)) != hipSuccess) { delete s; return e; }
-    for (int i = 0; i < 3; i++) if ((e = hipEventCreateWithFlags(&s->fj[i], hipEventDisableTiming)) != hipSuccess) { delete s; return e; }
+    for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking)) != hipSuccess) { delete s; return e; }
+    for (int i = 0; i < 4; i++) if ((e = hipEventCreateWithFlags(&s->fj[i], hipEventDisableTiming)) != hipSuccess) { delete s; return e; }
     p->sides = s;
     return hipSuccess;
 }
@@ -470,13 +470,13 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     if ((e = sdsm_launch_setup(P, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w, p->setup_class)) != hipSuccess) return hipfail(e, "launch setup");
     if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    hipStream_t s1 = nullptr, s2 = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
     hipEvent_t *fj = nullptr;
     if (p->n_order_c > 0 || p->n_order_d > 0 || p->n_order_w > 0) {
         if ((e = acquire_sides(p)) != hipSuccess) return hipfail(e, "side streams");
-        s1 = p->sides->side[0]; s2 = p->sides->side[1]; fj = p->sides->fj;
+        s1 = p->sides->side[0]; s2 = p->sides->side[1]; s3 = p->sides->side[2]; fj = p->sides->fj;
     }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, nullptr, fj, p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, s3, fj, p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }

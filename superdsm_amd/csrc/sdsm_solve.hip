@@ -1276,13 +1276,13 @@ __device__ __forceinline__ Frame make_frame(const Cand &c, int H, int W)
 
 }  // namespace
 
-// A candidate belongs to the FIRST class whose limits (6 + M <= NMAX and Hessian envelope <= EMAX doubles) it meets; the
-// limits of the previous class are passed at run time (nprev = 0 for the first class).  The first class also writes the
+// A candidate belongs to the FIRST class (1, 1b, 2, 2b, global memory) whose limits (6 + M <= NMAX and Hessian envelope <= EMAX
+// doubles) it meets; the limits of the previous class(es) are passed at run time (nprev = 0 for the first class).  The first class also writes the
 // records of trivial / failed-setup candidates.
 // WIDE: the launch list holds (candidate | member << 24) for every member of every workgroup group.
 template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false>
 __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records,
-                                                              uint32_t *masks, double *xi_out)
+                                                              uint32_t *masks, double *xi_out, int nprev2, int eprev2)
 {
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
     int tid = threadIdx.x;                                   // re-derived (opaque_tid) at the start of every section: nothing per-thread is kept across the solver
@@ -1322,6 +1322,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         const bool to_group = cd.wide_g > 0 && nfull <= SDSM_MAX_N_SOLVE && efull <= SDSM_K2_EMAX;
         if (to_group) return;                                                // solved by its workgroup group
         if (nfull <= nprev && efull <= eprev && cd.N <= pixprev) return;     // an earlier class took it
+        if (nfull <= nprev2 && efull <= eprev2) return;                      // (the limits of classes 2 and 2b are not nested: the class after them checks both)
         if (!(nfull <= NMAX && efull <= EMAX && cd.N <= pixmax)) return;     // a later class takes it
     }
     if (GLOBALH && cd.hglob_off < 0) {                          // cannot happen (the host reserves a slot whenever Mcap admits it)
@@ -1663,12 +1664,19 @@ extern "C" hipError_t sdsm_launch_eval(const BatchParams &P, const double *param
 }
 
 // ---- launch helper (called from sdsm_api.hip) ----------------------------------------------------
-// class 1: 6 + M <= 128, envelope <= 2560 doubles, <= P.k1_pixmax pixels   256 threads, LDS ~ 30 KB  (register bound: 2 workgroups / CU)
-// class 2: 6 + M <= 1024, envelope <= 11000 doubles 512 threads, LDS ~ 157 KB (1 workgroup / CU)
-// class 3: 6 + M <= 1024, any envelope              512 threads, Hessian in global memory (only launched when needed)
-// The classes are independent: they run concurrently on streams forked from the caller's stream.
+// class 1:  6 + M <= 128,  envelope <= 2560 doubles, <= P.k1_pixmax pixels   256 threads, LDS ~ 30 KB  (three workgroups / CU)
+// class 1b: 6 + M <= 256,  envelope <= 6144 doubles, <= P.k1_pixmax pixels   256 threads, LDS ~ 68 KB  (two workgroups / CU; 512-thread kernels need
+//           ~200 registers per thread, i.e. a whole compute unit per workgroup whatever their LDS)
+// class 2:  6 + M <= 1024, envelope <= 11000 doubles   512 threads, LDS ~ 157 KB (one workgroup / CU)
+// class 2b: 6 + M <= 512,  envelope <= 15900 doubles   512 threads, LDS ~ 160 KB (one workgroup / CU)
+// class 3:  6 + M <= 1024, any envelope                512 threads, Hessian in global memory (only launched when needed)
+// The classes are independent: they run concurrently on streams forked from the caller's stream.  Measured on the synthetic 4096^2
+// image (10 073 candidates; 2695 of them beyond class 1, 122 beyond class 2) before classes 1b / 2b existed: class 2 alone needed
+// 10.9 s of workgroup time at ONE workgroup per compute unit (43 ms), and the global-memory class, queued behind it on the same
+// stream, another 75 ms (52 ms per candidate: every atomic of the pixel pass goes to memory).
 template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false>
-static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
+static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
+                               int nprev2 = 0, int eprev2 = 0)
 {
     auto kern = sdsm_k_solve<NMAX, EMAX, WPE, GLOBALH, WGSIZE, WIDE>;
     constexpr int lds = Lay<NMAX, EMAX, GLOBALH, WGSIZE>::TOTAL_BYTES;
@@ -1682,12 +1690,12 @@ static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int p
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     if (P.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nprev, eprev, pixprev, pixmax, handles_rest, records, masks, xi_out);
+    hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nprev, eprev, pixprev, pixmax, handles_rest, records, masks, xi_out, nprev2, eprev2);
     return hipGetLastError();
 }
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
-                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 3 */,
+                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */,
                                         int n_c, int n_d, int n_w)
 {
     hipError_t e;
@@ -1698,29 +1706,35 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     Pw.order = P.order + P.n + n_c + n_d; Pw.n = n_w;                         // (candidate | member << 24) of the workgroup groups
     // fork: the side streams wait for everything queued on the caller's stream so far (setup kernel)
     if (n_c > 0 || n_d > 0 || n_w > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
-    if (n_w > 0) {   // very large regions: groups of 512-thread workgroups, launched first (the longest chains of the batch)
-        if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true>(Pw, 0, 0, 0, INT_MAX, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
-        if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
-    }
-    // classes 2 and 3 share ONE side stream (they are short lists that mostly exit at once; every extra stream per batch
-    // costs a hardware queue, and batches in flight beyond the queues serialise)
-    (void)side3;
-    if (n_c > 0 || n_d > 0) {
+    // Three queues, longest chains first on each (measured on the synthetic 4096^2 image; a fourth stream did not get a hardware queue
+    // of its own and waited behind another):
+    //   side1: the global-memory class (one candidate takes tens of milliseconds), then class 2b -- lists of the few candidates whose
+    //          bound on M admits them;
+    //   side2: the workgroup groups of the very large regions, then class 2;
+    //   caller's stream: class 1, then class 1b (both 256 threads per candidate, several workgroups per compute unit).
+    // The lists of the larger classes are upper bounds (the host knows a bound on M, not M): most of their workgroups exit at once.
+    if (n_d > 0) {
         if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
-        if (n_c > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512>(Pc, SDSM_K1_NMAX, SDSM_K1_EMAX, P.k1_pixmax, INT_MAX, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-        if (n_d > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, INT_MAX, INT_MAX, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, INT_MAX, INT_MAX, 0, records, masks, xi_out, side1,
+                                                                                                              SDSM_K2B_NMAX, SDSM_K2B_EMAX)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, INT_MAX, INT_MAX, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
     }
-    // class 1 at THREE wavefronts per SIMD (168 registers; measured 6.54 vs 7.43 ms at two: the solver is latency bound and a third
-    // workgroup per compute unit fills its stalls, at the price of ~35 spilled registers; four -- 128 registers -- spill 73: 10.9 ms)
+    if (n_w > 0 || n_c > 0) {
+        if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
+        if (n_w > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true>(Pw, 0, 0, 0, INT_MAX, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
+        if (n_c > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512>(Pc, SDSM_K1B_NMAX, SDSM_K1B_EMAX, P.k1_pixmax, INT_MAX, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
+    }
     // class 1 runs THREE wavefronts per SIMD (168 registers, no scratch: the sparse pass loads the row of G~ twice instead of
     // holding it across the loss evaluation).  Measured on the 8-image launch: 7.4 ms at two wavefronts (240 registers), 5.5 ms at
     // three, 6.6 ms at four (128 registers: 36 spilled, in the line-search and atomics loops) -- the solver is latency bound and a
     // third workgroup per compute unit fills its stalls.
     if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
+    if (n_c > 0 && (e = launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, 2, false, 256>(Pc, SDSM_K1_NMAX, SDSM_K1_EMAX, P.k1_pixmax, P.k1_pixmax, 0, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
-    if ((n_c > 0 || n_d > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
-    if (n_w > 0 && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
+    if (n_d > 0 && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
+    if ((n_w > 0 || n_c > 0) && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
+    (void)side3;
     return hipSuccess;
 }
