@@ -763,6 +763,11 @@ def test_synthetic4096_matches_oracle(gpu):
     sample = set(order[-12:].tolist()) | set(order[:6].tolist()) | set(order[len(order) // 2 - 3:len(order) // 2 + 3].tolist())
     sample |= set(np.argsort(recs['n_deform'])[-10:].tolist()) | set(np.argsort(its)[-12:].tolist())
     sample |= set(np.random.default_rng(4).choice(len(fps), 40, replace=False).tolist())
+    # the solve classes between the common one and the global-memory one (1b: 6 + M <= 256, 2 / 2b: up to 512 with their envelope in LDS)
+    for lo, hi in ((129, 200), (201, 256), (257, 340), (341, 512)):
+        pool = np.flatnonzero((n >= lo) & (n <= hi))
+        assert pool.size, (lo, hi)
+        sample |= set(np.random.default_rng(lo).choice(pool, min(5, pool.size), replace=False).tolist())
     sample = sorted(sample)
     assert len(sample) >= 64
     orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], [fps[i] for i in sample], scene['dsm_cfg'], nthreads=0)
