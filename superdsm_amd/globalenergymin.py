@@ -23,7 +23,7 @@ from .output import Text, get_output
 from .pipeline import Stage
 
 DEFAULT_MAX_WORK_AMOUNT = 10 ** 6
-DEFAULT_SPECULATION = 2            # generations solved ahead per GPU batch (extension; 0 = the reference's batches exactly)
+DEFAULT_SPECULATION = 3            # generations solved ahead per GPU batch (extension; 0 = the reference's batches exactly)
 DEFAULT_SPECULATION_BUDGET = 768   # ... while the batch stays within what one MI355X runs at once (256 compute units x 3 workgroups)
 
 
@@ -303,9 +303,10 @@ class _Speculation:
         for o, k in zip(objects, keys):
             src = self.store[k]
             if src is not o:
-                footprint = o.footprint
-                o.set(src)
-                o.footprint = footprint
+                # (the fragment array is shared, not copied as Object.set would: results are replaced, never modified in place)
+                o.fg_offset, o.fg_fragment = src.fg_offset, src.fg_fragment
+                o.energy, o.on_boundary, o.is_optimal, o.processing_time = src.energy, src.on_boundary, src.is_optimal, src.processing_time
+                o.cvxprog_region_size = getattr(src, 'cvxprog_region_size', 0)
             if k in self.unasked:
                 self.unasked.discard(k)
                 self.served += 1
