@@ -194,6 +194,9 @@ static uint32_t perm_inverse(uint32_t N)
 #ifndef SDSM_LAT_GMAX
 #define SDSM_LAT_GMAX 4
 #endif
+#ifndef SDSM_WIDE_MAX_MEMBERS
+#define SDSM_WIDE_MAX_MEMBERS 256    // throughput mode: group members of one launch (= compute units of an MI355X); the largest regions first
+#endif
 // Workgroup groups, launch lists and workspace layout (repeated when the scheduling mode changes).
 static void layout_plan(sdsm_plan *p)
 {
@@ -202,10 +205,27 @@ static void layout_plan(sdsm_plan *p)
     p->wide_pixels = latency ? SDSM_WIDE_PIXELS : INT_MAX;
     p->layout_gen++;
     p->n_wide = 0;
+    // Groups shorten the longest chains of a launch; every member holds a whole compute unit and a group only advances while all of its
+    // members are resident.  In throughput mode the LARGEST regions get groups until their members add up to the compute units of the
+    // chip; very large regions beyond that (synthetic 4096^2 image: 434 of them, 1296 members -- they waited for each other behind the
+    // small classes) are solved as ordinary class-2 candidates, one workgroup each.
+    std::vector<char> grouped(n, 1);
+    if (groups && !latency) {
+        std::vector<int> big;
+        for (int i = 0; i < n; i++) if (p->cand[i].N > SDSM_WIDE_MIN_PIXELS) big.push_back(i);
+        std::stable_sort(big.begin(), big.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
+        long members = 0;
+        int cutoff = 0;                                  // regions of at most this many pixels get no group (equal regions are treated alike)
+        for (int i : big) {
+            members += std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (p->cand[i].N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
+            if (members > SDSM_WIDE_MAX_MEMBERS) { cutoff = p->cand[i].N; break; }
+        }
+        for (int i : big) if (p->cand[i].N <= cutoff) grouped[i] = 0;
+    }
     for (int i = 0; i < n; i++) {
         CandDesc &c = p->cand[i];
         long G = 0;
-        if (groups && n < (1 << 24)) {
+        if (groups && grouped[i] && n < (1 << 24)) {
             if (c.N > SDSM_WIDE_MIN_PIXELS) G = std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (c.N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
             else if (latency && c.N > SDSM_WIDE_PIXELS) G = std::min<long>(SDSM_LAT_GMAX, std::max<long>(2, (c.N + SDSM_LAT_SLICE - 1) / SDSM_LAT_SLICE));   // latency mode: the largest regions of an ordinary image too
         }
