@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the stage / compute_objects / preprocessing timings')
     ap.add_argument('--inflight', type=int, default=1, help='independent steps in flight on separate streams (1 = strictly sequential launches)')
+    ap.add_argument('--images-workload-explicit', action='store_true', help='image_set mode: take --workload literally (default: bbbc039_like means the NIH3T3-like set of BASELINE.json configs[3])')
+    ap.add_argument('--ranks-per-gpu', type=int, default=1, help='worker processes per GPU (image sets are host bound per process: several processes share a card; gloo moves the small results)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous and reporting only, no GPU work (CPU test of the N-rank plumbing)')
     return ap.parse_args()
 
@@ -61,8 +63,8 @@ def spawn_ranks(args):
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    for r in range(args.gpus * args.ranks_per_gpu):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus * args.ranks_per_gpu), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -159,7 +161,7 @@ def measured_traffic(workload, n_images):
 # ---------------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if args.gpus * args.ranks_per_gpu > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
     if args.inflight > 4:
         os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # ROCm maps streams onto 4 hardware queues by default
@@ -170,7 +172,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     ndev = torch.cuda.device_count()                           # (does not initialise the GPU)
     # fewer GPUs than ranks (rehearsal on a one-GPU box) or no GPU at all (--dry-run on a CPU box): gloo moves host memory
-    backend = os.environ.get('SDSM_BENCH_BACKEND', 'nccl' if ndev >= world and not args.dry_run else 'gloo')
+    rpg = max(1, args.ranks_per_gpu)
+    backend = os.environ.get('SDSM_BENCH_BACKEND', 'nccl' if ndev * rpg >= world and rpg == 1 and not args.dry_run else 'gloo')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -180,14 +183,14 @@ def main():
             dist.barrier()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if rank == 0:
-            print(json.dumps({'metric': 'candidate DSM solves/sec', 'value': 0.0, 'unit': 'candidate solves/s', 'n_gpus': world, 'steps': args.steps,
+            print(json.dumps({'metric': 'candidate DSM solves/sec', 'value': 0.0, 'unit': 'candidate solves/s', 'n_gpus': max(1, world // rpg), 'steps': args.steps,
                               'warmup': args.warmup, 'ms_per_step': float(t.item()), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                               'dtype': 'f64', 'data': 'none (dry run of the rank plumbing)', 'config': {'workload': 'dry-run', 'backend': backend}}))
         if world > 1:
             dist.destroy_process_group()
         return
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the DSM solve path has no CPU fallback)'
-    torch.cuda.set_device(local_rank % ndev)
+    torch.cuda.set_device((local_rank // rpg) % ndev)
     if args.mode == 'image_set':
         return image_set_mode(args, world, rank, backend)
 
@@ -264,7 +267,7 @@ def main():
     z = 11.0
     flops = float((evals * recs['n_pixels'] * (4 * (6 + z) + 20)).sum() + (recs['evals_full'].astype(np.int64) * recs['n_pixels'] * (6 + z) ** 2).sum())
     out = {
-        'metric': 'candidate DSM solves/sec', 'value': value, 'unit': 'candidate solves/s', 'n_gpus': world, 'steps': args.steps,
+        'metric': 'candidate DSM solves/sec', 'value': value, 'unit': 'candidate solves/s', 'n_gpus': max(1, world // rpg), 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'{args.workload} {scene["y"].shape[0]}x{scene["y"].shape[1]} (BASELINE.json configs[1] stand-in: ellipses at the centres/areas of a '
@@ -272,7 +275,7 @@ def main():
                                f'subsets of size <= {args.max_size} + cluster universes',
                    'images_per_step': n_images, 'candidates_per_image': len(fps1), 'candidates_per_step_per_gpu': len(fps), 'atoms_per_image': int(scene['atoms'].max()),
                    'median_N': int(np.median(recs['n_pixels'])), 'median_M': int(np.median(recs['n_deform'])),
-                   'parallelism': f'{world} x (1 process per GPU), weak scaling: every rank solves its own images, one RCCL gather of records + masks per step'
+                   'parallelism': f'{world} ranks ({rpg} per GPU), weak scaling: every rank solves its own images, one gather of records + masks per step (RCCL with one rank per GPU)'
                                   if world > 1 else 'single GPU',
                    'steps_in_flight': nfl, 'timed_regions_ms': region_ms, 'value_is': 'median over the timed regions'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
@@ -398,8 +401,8 @@ def image_set_mode(args, world, rank, backend):
     import torch.distributed as dist
     from superdsm_amd import config, globalenergymin, testing
     from superdsm_amd import dist as sdist
-    wl = args.workload if args.workload != 'bbbc039_like' else 'nih3t3_like'
-    scene = testing.make_scene(wl, max_size=2)
+    wl = args.workload if args.workload != 'bbbc039_like' or args.images_workload_explicit else 'nih3t3_like'
+    scene = testing.make_scene(wl, max_size=2 if wl != 'bbbc039_like' else 3)
     n_images = (args.images or 4) * world
     mine = sdist.deal_images(n_images, world)[rank]
     beta = {'nih3t3_like': 1200.0, 'gowt1_like': 1188.0}.get(wl, 150.0)
@@ -432,11 +435,12 @@ def image_set_mode(args, world, rank, backend):
         flat = sorted(x for part in got for x in part)
         ncand = sum(x[3] for x in flat)
         print(json.dumps({
-            'metric': 'candidate DSM solves/sec', 'value': ncand / dt, 'unit': 'candidate solves/s', 'n_gpus': world, 'steps': 1, 'warmup': 1,
+            'metric': 'candidate DSM solves/sec', 'value': ncand / dt, 'unit': 'candidate solves/s', 'n_gpus': max(1, world // max(1, args.ranks_per_gpu)), 'steps': 1, 'warmup': 1,
             'ms_per_step': dt * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{wl} image set (BASELINE.json configs[3] stand-in): {n_images} images of {scene["y"].shape[0]}x{scene["y"].shape[1]}, '
-                                   f'{n_images // world} per GPU, global-energy-minimisation stage in lock step, one gather of the results at the end',
-                       'images': n_images, 'candidates_solved': ncand, 'wall_ms_per_image': dt * 1e3 / (n_images // world), 'objects_in_covers': sum(len(x[1]) for x in flat)},
+                                   f'{n_images // world} per rank, global-energy-minimisation stage in lock step, one gather of the results at the end',
+                       'images': n_images, 'candidates_solved': ncand, 'ranks_per_gpu': max(1, args.ranks_per_gpu), 'wall_ms_per_image_and_rank': dt * 1e3 / (n_images // world),
+                       'wall_ms_per_image': dt * 1e3 / n_images * max(1, world // max(1, args.ranks_per_gpu)), 'objects_in_covers': sum(len(x[1]) for x in flat)},
             'roofline': None, 'cpu_baseline': None}))
     if world > 1:
         dist.destroy_process_group()
