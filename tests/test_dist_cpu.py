@@ -171,3 +171,19 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['ms_per_step'] == 2.0      # MAX over the ranks' (1 + rank)
+
+
+def test_bench_ranks_per_gpu_starts_that_many_processes_per_card():
+    """`--ranks-per-gpu R`: R worker processes per GPU (an image set is host bound per process); n_gpus stays the number of GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--ranks-per-gpu', '3', '--dry-run'],
+                         env=env, capture_output=True, timeout=180)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 1 and out['ms_per_step'] == 3.0 and out['config']['backend'] == 'gloo'      # MAX over the three ranks' (1 + rank)
