@@ -232,7 +232,7 @@ class _Speculation:
     The generations of an image are sequential (the thresholds of generation k + 1 need the energies of generation k,
     globalenergymin.py:326-368) and hold tens of candidates each, while one batch of the engine takes as long as its largest
     region whether it has 20 or 500 candidates (a single image uses a fraction of an MI355X): solving the next generation
-    for ALL parents, before it is known which of them survive the pruning, turns two dependent round trips into one.  The host
+    for ALL parents, before it is known which of them survive the pruning, turns two dependent round trips into one.
     A batch is only extended while it stays within ``budget`` candidates -- what the GPU runs concurrently; beyond that the extra
     candidates would cost time instead of hiding latency (image sets in lock step share the budget).  The host
     logic is unchanged and sees the same candidates with the same results; candidates solved in vain are not counted in the
