@@ -246,6 +246,13 @@ class _Speculation:
         self.store = {}                                     # frozenset(footprint) -> solved Object
         self.batches = self.extra = self.served = 0         # GPU batches, candidates solved ahead, those of them asked for later
         self.unasked = set()                                # solved ahead, not asked for (yet)
+        # host work to do while a batch is on the GPU (set by the caller): handed to operators that take a `while_waiting` argument
+        self.while_waiting = None
+        try:
+            import inspect
+            self.accepts_callback = 'while_waiting' in inspect.signature(solve).parameters
+        except (TypeError, ValueError):
+            self.accepts_callback = False
 
     def _children(self, parents, limit):
         """Footprints of the next ``depth`` generations of ``parents``, level by level; a level that would take the batch beyond
@@ -283,8 +290,9 @@ class _Speculation:
                 if error.cidx is not None and error.cidx < len(missing):
                     error.cidx = next(i for i, o in enumerate(objects) if o is missing[error.cidx])
                 return error
+            extra = dict(while_waiting=self.while_waiting) if self.accepts_callback and self.while_waiting is not None else {}
             try:
-                self.solve(missing + ahead, y, atoms, dsm_cfg, log_root_dir, status_line, out=out, shard=shard)
+                self.solve(missing + ahead, y, atoms, dsm_cfg, log_root_dir, status_line, out=out, shard=shard, **extra)
             except CvxprogError as error:
                 if error.cidx is None or error.cidx < len(missing):
                     raise renumber(error)
@@ -323,7 +331,7 @@ def _process_generation(cover, objects, previous_generation, y, atoms_map, adjac
                                                            lambda c: c.footprint, ignored_cluster_labels, skip_last=True, memo=memo):
         cluster = adjacencies.get_cluster_label(next(iter(parent.footprint)))
         if cluster != last_cluster:
-            last_cluster, cluster_costs = cluster, cover.get_cluster_costs(cluster)
+            last_cluster, cluster_costs = cluster, (cover.get_cluster_costs(cluster) if pruning == 'exact' else None)   # (isbi24 does not look at the cover)
         candidate = Object()
         candidate.footprint = footprint
         if pruning == 'exact':
@@ -432,6 +440,21 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
     performance.iterative_object_count = first(solved_directly)[1]
     performance.overall_computed_object_count = len(objects)
 
+    # With 'isbi24' pruning the thresholds of a generation do not depend on the cover (globalenergymin.py:344-347), only the final
+    # result does: its updates -- one min-weight set cover per touched cluster and generation -- are then applied, in order, while the
+    # next batch is on the GPU instead of between the batches.  (Not with a log that shows the costs after every iteration, not with
+    # 'exact' pruning, whose bounds read the cover, and not when the operator cannot call back.)
+    pending = []
+
+    def flush_cover():
+        for generation in pending:
+            cover.update(generation, out.derive(muted=True))
+            costs.append(cover.costs)
+        del pending[:]
+
+    defer_cover = pruning == 'isbi24' and getattr(out, 'muted', False) and ahead is not None and ahead.accepts_callback
+    if defer_cover:
+        ahead.while_waiting = flush_cover
     if len(solved_directly) < len(adjacencies.cluster_labels):
         while True:
             number = 1 + len(generations)
@@ -448,9 +471,13 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
             if not new_generation:
                 break
             generations.append(new_generation)
-            cover.update(new_generation, out.derive(muted=True))
-            costs.append(cover.costs)
-            out.write(f'Solution costs: {costs[-1]:,g}')
+            if defer_cover:                                 # applied, in order, while the next batch is on the GPU (or at the end)
+                pending.append(new_generation)
+            else:
+                cover.update(new_generation, out.derive(muted=True))
+                costs.append(cover.costs)
+                out.write(f'Solution costs: {costs[-1]:,g}')
+        flush_cover()
 
     performance.nontrivial_computed_object_count += performance.iterative_computed_object_count
     performance.overall_computed_object_count += performance.iterative_computed_object_count

@@ -143,7 +143,7 @@ def _write_logs(log_root_dir, records):
                     f'theta: {np.asarray(r["theta"]).tolist()}\n')
 
 
-def _solve(images, footprints, image_of, cfg, shard):
+def _solve(images, footprints, image_of, cfg, shard, while_waiting=None):
     """One batch over one or several images -> (records, fragments).  Candidates whose workgroup group was given up (a
     scheduling event on an oversubscribed GPU, not a solver failure) are solved again without groups."""
     from . import engine
@@ -154,6 +154,8 @@ def _solve(images, footprints, image_of, cfg, shard):
     batch = engine.Batch(images if len(images) > 1 else images[0], footprints, cfg, image_of=image_of,
                          mode=1 if len(images) == 1 else 0)        # one image at a time: shortest wall clock; several: fill the GPU
     batch.launch()
+    if while_waiting is not None:                          # host work of the caller while the kernels run (the launch is asynchronous)
+        while_waiting()
     records, masks = batch.download()
     records = records.copy()
     fragments = batch.fragments(records, masks=masks)
@@ -209,7 +211,7 @@ def _clean_cfg(dsm_cfg):
     return cfg
 
 
-def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, shard=None):
+def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, shard=None, while_waiting=None):
     """Computes ``energy``, ``on_boundary``, ``is_optimal``, ``processing_time``, ``fg_offset`` and ``fg_fragment`` of
     every object IN PLACE (objects.py:243-267).
 
@@ -219,18 +221,24 @@ def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAUL
     :param dsm_cfg: the ``dsm/*`` hyper-parameters (dsmcfg.py:6-21).
     :param log_root_dir: directory that receives one ``<cidx>.txt`` per candidate (objects.py:220-237), or ``None``.
     :param shard: optional :class:`superdsm_amd.dist.Sharder`: solve only this rank's share, all-gather the results.
+    :param while_waiting: optional callable (extension): host work of the caller, run once after the batch has been launched and before
+        its results are waited for (the launch is asynchronous); exceptions it raises propagate.
     """
     out = get_output(out)
     objects = list(objects)
     cfg = _clean_cfg(dsm_cfg)
     if len(objects) == 0:
+        if while_waiting is not None:
+            while_waiting()
         out.write(f'{status_line[1]}: 0 (0x fallback)')
         return
     margin = cfg.pop('background_margin', 20)
     image = device_image(y, atoms, margin)
     out.intermediate(f'{status_line[0]}... 0 / {len(objects)}')
     t0 = time.time()
-    records, fragments = _solve([image], [obj.footprint for obj in objects], None, cfg, shard)
+    records, fragments = _solve([image], [obj.footprint for obj in objects], None, cfg, shard, while_waiting if shard is None else None)
+    if shard is not None and while_waiting is not None:
+        while_waiting()
     dt = time.time() - t0
     _write_logs(log_root_dir, records)
     fallbacks = _assign(objects, records, fragments, dt)

@@ -253,12 +253,17 @@ def test_generations_solved_ahead_change_nothing_but_the_number_of_batches(pruni
         base = sum(30 + 20 * h(f'a{a}') for a in fp)
         return base if len(fp) == 1 else base * (0.75 + 0.5 * h(','.join(map(str, fp))))
 
-    def run(depth, poison=None, budget=768):
+    waited = []
+
+    def run(depth, poison=None, budget=768, callback=False):
         calls = []
 
-        def fake(objs, y, atoms_map, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None):
+        def fake(objs, y, atoms_map, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None, **kwargs):
             objs = list(objs)
             calls.append([frozenset(o.footprint) for o in objs])
+            if kwargs.get('while_waiting') is not None:
+                waited.append(len(calls))
+                kwargs['while_waiting']()
             for k, o in enumerate(objs):
                 if poison is not None and frozenset(o.footprint) == poison:
                     raise objects.CvxprogError('convex programming failed for the elliptical model', cidx=k)
@@ -266,7 +271,10 @@ def test_generations_solved_ahead_change_nothing_but_the_number_of_batches(pruni
                 o.is_optimal, o.on_boundary, o.processing_time = True, False, 0
                 o.fg_offset, o.fg_fragment = np.zeros(2, int), np.zeros((1, 1), bool)
 
-        monkeypatch.setattr(globalenergymin, 'compute_objects', fake)
+        if callback:                                          # an operator that takes `while_waiting`, as objects.compute_objects does
+            def fake_cb(objs, y, atoms_map, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None, while_waiting=None):
+                return fake(objs, y, atoms_map, dsm_cfg, log_root_dir, status_line, out=out, shard=shard, while_waiting=while_waiting)
+        monkeypatch.setattr(globalenergymin, 'compute_objects', fake_cb if callback else fake)
         gens, costs, cover, objs, perf = globalenergymin._compute_generations(adj, None, scene['atoms'], None, pruning, {}, beta=5.0, out='muted', speculation=depth,
                                                                               speculation_budget=budget)
         state = ([sorted(sorted(o.footprint) for o in g) for g in gens], [sorted(o.footprint) for o in objs], [o.energy for o in objs], list(costs),
@@ -281,6 +289,10 @@ def test_generations_solved_ahead_change_nothing_but_the_number_of_batches(pruni
         assert state == plain
         assert len(calls) < len([c for c in plain_calls if c]) and perf.engine_batches == len(calls)
         assert perf.speculative_object_count == sum(len(c) for c in calls) - sum(len(c) for c in plain_calls)
+    # the set-cover updates of a generation applied while the next batch is "on the GPU" (an operator with `while_waiting`; isbi24 only)
+    state, calls, _ = run(1, callback=True)
+    assert state == plain
+    assert bool(waited) == (pruning == 'isbi24')
     # a batch is only extended within the budget (what the GPU runs at once): all or nothing
     state, calls, _ = run(1, budget=60)
     assert state == plain and all(len(c) <= 60 or c in plain_calls or c == plain_calls[0] + plain_calls[1] for c in calls)
