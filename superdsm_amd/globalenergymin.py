@@ -394,6 +394,12 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         obj.footprint = set(adjacencies.get_atoms_in_cluster(cluster))
         universes.append(obj)
     out.write('\nIteration 1:')
+    # the size of the search space (for the PerformanceReport) only needs the adjacency graph: counted while the first batch is on the GPU
+    early = {}
+    if ahead is not None and ahead.accepts_callback:
+        def count_search_space():
+            early['by_cluster'] = _remaining_by_cluster([atoms], adjacencies, max_seed_distance, max_amount=max_work_amount, skip_last=True, memo=memo)
+        ahead.while_waiting = count_search_space
     if log_root_dir is None and (ahead is not None or (shard is None and getattr(compute_objects, '__module__', None) == Object.__module__)):   # (not when a test substitutes the operator)
         # the atoms and the cluster universes do not depend on each other (globalenergymin.py:192,199 computes them one after the
         # other): ONE batch of the engine -- a batch costs a round trip to the GPU whatever its size.  (With per-candidate log
@@ -408,6 +414,8 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
         solve(atoms, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 1), out=out, shard=shard)
         solve(universes, y_img, atoms_map, dsm_cfg, _generation_log_dir(log_root_dir, 0),
               ('Computing universe costs', 'Universe costs computed'), out=out, shard=shard)
+    if ahead is not None:
+        ahead.while_waiting = None
     atom_by_label = {next(iter(a.footprint)): a for a in atoms}
 
     solved_directly, trivial = set(), set()        # Criterion 2 / universes of one or two atoms
@@ -432,7 +440,7 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
     objects = atoms + universes
     progress = lambda ignored: _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=max_work_amount,
                                                   ignored_cluster_labels=ignored, skip_last=True, memo=memo)
-    by_cluster = _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amount=max_work_amount, skip_last=True, memo=memo)
+    by_cluster = early['by_cluster'] if 'by_cluster' in early else _remaining_by_cluster(generations, adjacencies, max_seed_distance, max_amount=max_work_amount, skip_last=True, memo=memo)
     first = lambda ignored: _estimate_progress(generations, adjacencies, max_seed_distance, max_amount=max_work_amount,
                                                ignored_cluster_labels=ignored, skip_last=True, by_cluster=by_cluster)
     performance.nontrivial_object_count = first(trivial)[1]      # (one enumeration for both counts: a footprint stays in its cluster)
