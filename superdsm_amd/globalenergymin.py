@@ -510,13 +510,20 @@ class _LockStep:
         self.cv = threading.Condition()
         self.batches = 0                      # multi-image batches solved (diagnostics / tests)
 
-    def submit(self, objects, y, atoms, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None):
+    def submit(self, objects, y, atoms, dsm_cfg, log_root_dir, status_line=None, out=None, shard=None, while_waiting=None):
+        """``while_waiting``: host work of the calling thread that does not need the results (compute_objects): the thread that
+        completes the rendezvous runs it after the batch has been launched, the others right after submitting -- so the batch
+        starts as soon as the last image has its candidates, and whatever host work is left overlaps with it."""
         assert shard is None, 'process_many and sharded batches are separate ways to fill the GPUs'
         with self.cv:
             my_round = self.round
             self.jobs.append((list(objects), y, atoms, dsm_cfg, log_root_dir))
-            if len(self.jobs) >= self.active:
-                self._flush()
+            last = len(self.jobs) >= self.active
+            if last:
+                self._flush(while_waiting)
+        if not last and while_waiting is not None:
+            while_waiting()                                  # (outside the lock)
+        with self.cv:
             while self.round == my_round and self.error is None:
                 self.cv.wait()
             if self.error is not None:
@@ -528,17 +535,17 @@ class _LockStep:
             if self.jobs and len(self.jobs) >= self.active:
                 self._flush()
 
-    def _flush(self):
+    def _flush(self, while_waiting=None):
         jobs, self.jobs = self.jobs, []
         try:
             cfg = jobs[0][3]
             assert all(j[3] == cfg for j in jobs), 'the images of one lock-step run share the dsm/* hyper-parameters'
             if self.stream is None:
-                compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out)
+                compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out, while_waiting=while_waiting)
             else:
                 import torch
                 with torch.cuda.stream(self.stream):
-                    compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out)
+                    compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out, while_waiting=while_waiting)
             self.batches += 1
         except BaseException as e:               # noqa: BLE001 -- handed to every waiting thread
             self.error = e

@@ -245,7 +245,7 @@ def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAUL
     out.write(f'{status_line[1]}: {len(objects)} ({fallbacks}x fallback)')
 
 
-def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None):
+def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, while_waiting=None):
     """:func:`compute_objects` for several images at once: ``jobs`` is a list of ``(objects, y, atoms)``, all solved as ONE
     batch of the engine (sdsm_plan_create_multi) -- the batches of a single small image (tens of candidates per generation,
     globalenergymin.py:357) cannot fill a GPU, the same generation of several images can.  Results are set in place, job by job;
@@ -265,7 +265,8 @@ def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT
             fps.extend(obj.footprint for obj in jobs[j][0])
             image_of.extend([k] * len(jobs[j][0]))
         t0 = time.time()
-        records, fragments = _solve(images, fps, np.asarray(image_of, np.int32), cfg, None)
+        records, fragments = _solve(images, fps, np.asarray(image_of, np.int32), cfg, None, while_waiting)
+        while_waiting = None                                 # (once: while the first batch is on the GPU)
         dt = time.time() - t0
         pos = 0
         for j in group:
@@ -277,5 +278,7 @@ def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT
             fb += per_job[j]
             pos += len(objs)
             total += len(objs)
+    if while_waiting is not None:                            # (no batch at all: nothing to wait for)
+        while_waiting()
     out.write(f'{status_line[1]}: {total} ({fb}x fallback)')
     return per_job
