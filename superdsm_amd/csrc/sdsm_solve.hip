@@ -47,6 +47,13 @@ namespace {
 #define ZREG (4 * SDSM_ELL_GROUPS_REG)   // ELL slots held in registers by the sparse path (covers zcap = 25 of the default ratios)
 #ifndef SDSM_FACTOR_DIV
 #define SDSM_FACTOR_DIV 1
+#ifndef SDSM_K1_THREADS
+#define SDSM_K1_THREADS 192
+#endif
+#ifndef SDSM_K1B_THREADS
+#define SDSM_K1B_THREADS 256       // (384 threads at three wavefronts per SIMD: synthetic 4096^2 93 vs 84 ms)
+#define SDSM_K1B_WPE 2
+#endif
 #endif
 #define HZREG 12         // leading ('significant') slots unrolled for the approximate Hessian
 
@@ -1730,8 +1737,13 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     // holding it across the loss evaluation).  Measured on the 8-image launch: 7.4 ms at two wavefronts (240 registers), 5.5 ms at
     // three, 6.6 ms at four (128 registers: 36 spilled, in the line-search and atomics loops) -- the solver is latency bound and a
     // third workgroup per compute unit fills its stalls.
-    if ((e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream)) != hipSuccess) return e;
-    if (n_c > 0 && (e = launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, 2, false, 256>(Pc, SDSM_K1_NMAX, SDSM_K1_EMAX, P.k1_pixmax, P.k1_pixmax, 0, records, masks, xi_out, stream)) != hipSuccess) return e;
+    // Throughput mode: 192 threads per candidate, FOUR workgroups per compute unit (the same twelve wavefronts; one more independent
+    // candidate per compute unit, whose barriers stall three wavefronts instead of four: 5.43 -> 5.10 ms on the 8-image launch).
+    // Latency mode (one image at a time, a batch is as slow as its slowest candidate): 256 threads per candidate.
+    if (P.k1_pixmax == INT_MAX) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream);
+    else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream);
+    if (e != hipSuccess) return e;
+    if (n_c > 0 && (e = launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, SDSM_K1B_WPE, false, SDSM_K1B_THREADS>(Pc, SDSM_K1_NMAX, SDSM_K1_EMAX, P.k1_pixmax, P.k1_pixmax, 0, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
     if (n_d > 0 && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
     if ((n_w > 0 || n_c > 0) && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
