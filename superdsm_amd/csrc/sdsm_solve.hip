@@ -1185,7 +1185,11 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
                 tau = 0; retries = 0;
             }
             double lam2u;
+            // the factorisation is a chain of dependent panels (LDS round trips, barriers): its wavefronts go first when the SIMD picks an
+            // instruction, ahead of the pixel passes of the other candidates of the compute unit, which have independent work to hide in (+1 %)
+            __builtin_amdgcn_s_setprio(3);
             const int fs = factor_solve<L>(c, M, tau, &lam2u PROF_ARG);
+            __builtin_amdgcn_s_setprio(0);
             if (fs == 1 && retries < 11) {                   // escalating diagonal shift (same schedule as the oracle)
                 retries++;
                 tau = uni(tau == 0 ? fresh(1e-12) : tau * fresh(100.0));
