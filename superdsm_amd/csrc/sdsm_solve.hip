@@ -392,6 +392,7 @@ __device__ __forceinline__ double eval_value(const Cand &c, int xo, int M)
 {
     const double *xv = SD + xo;
     double psi = 0;
+    __builtin_amdgcn_s_setprio(0);
     for (int p = c.p_lo + opaque_tid(); p < c.p_hi; p += L::WGS) {
         double yv = c.crop_y[p];
         uint32_t rc = c.crop_rc[p];
@@ -400,6 +401,7 @@ __device__ __forceinline__ double eval_value(const Cand &c, int xo, int M)
         if (M > 0) S += smooth_term(c, xv, p);
         psi += softplus_neg(yv * S);
     }
+    __builtin_amdgcn_s_setprio(2);
     psi = block_sum<L::NWAVES>(psi, SD + L::RED);
     if (c.wG > 1) {
         double *tmp = SD + L::TMP;
@@ -436,6 +438,7 @@ __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, doubl
 #pragma unroll
     for (int k = 0; k < LS_K; k++) ps[k] = 0;
     const bool in_regs = c.zmax <= ZREG;
+    __builtin_amdgcn_s_setprio(0);
     for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
         const double yv = c.crop_y[p];
         const uint32_t rc = c.crop_rc[p];
@@ -478,6 +481,7 @@ __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, doubl
             tk *= LS_BETA;
         }
     }
+    __builtin_amdgcn_s_setprio(2);
     block_sum_vec<LS_K, L::NWAVES>(ps, SD + L::RED);
     if (c.wG > 1) {
         double *tmp = SD + L::TMP;
@@ -597,6 +601,7 @@ __device__ __forceinline__ double eval_full_ell(const Cand &c PROF_PARAM)
     double red[NMOM];
 #pragma unroll
     for (int k = 0; k < NMOM; k++) red[k] = 0;
+    __builtin_amdgcn_s_setprio(0);
     for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
         const double yv = c.crop_y[p];
         const uint32_t rc = c.crop_rc[p];
@@ -606,6 +611,7 @@ __device__ __forceinline__ double eval_full_ell(const Cand &c PROF_PARAM)
         loss_terms(yv, Sv, &phi, &r, &dc);
         add_moments(red, phi, r, dc, u, v);
     }
+    __builtin_amdgcn_s_setprio(2);
     PROF_ADD(0, pt);
     double *tot = SD + L::TMP;                           // TMP is free outside factor_solve
     moments_total<L>(red, tot);
@@ -680,6 +686,7 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
         double red[NMOM];                                // psi and the coordinate moments of r and d (add_moments)
 #pragma unroll
         for (int k = 0; k < NMOM; k++) red[k] = 0;
+        __builtin_amdgcn_s_setprio(0);
         for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
             FINE_START();
             const double yv = c.crop_y[p];
@@ -754,6 +761,7 @@ __device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double 
             }
             FINE_ADD(12);
         }
+        __builtin_amdgcn_s_setprio(2);
         PROF_ADD(0, pt);
         moments_total<L>(red, tot);                      // (its barriers: every atomic of the pass has landed)
     }
@@ -1185,11 +1193,9 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
                 tau = 0; retries = 0;
             }
             double lam2u;
-            // the factorisation is a chain of dependent panels (LDS round trips, barriers): its wavefronts go first when the SIMD picks an
-            // instruction, ahead of the pixel passes of the other candidates of the compute unit, which have independent work to hide in (+1 %)
             __builtin_amdgcn_s_setprio(3);
             const int fs = factor_solve<L>(c, M, tau, &lam2u PROF_ARG);
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(2);
             if (fs == 1 && retries < 11) {                   // escalating diagonal shift (same schedule as the oracle)
                 retries++;
                 tau = uni(tau == 0 ? fresh(1e-12) : tau * fresh(100.0));
@@ -1296,6 +1302,10 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
                                                               uint32_t *masks, double *xi_out, int nprev2, int eprev2)
 {
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
+    // Issue priority: the passes over the pixels run at 0, everything between them -- reductions, the Newton bookkeeping, mask tail --
+    // at 2 and the factorisation at 3: the serial sections of a candidate (dependent LDS round trips, barriers) go first when a SIMD
+    // picks an instruction, the pixel passes of the other candidates of the compute unit fill the gaps (+2 % on the 8-image launch).
+    __builtin_amdgcn_s_setprio(2);
     int tid = threadIdx.x;                                   // re-derived (opaque_tid) at the start of every section: nothing per-thread is kept across the solver
     int slot = blockIdx.x;
     if (WIDE) {                                              // members are claimed in start order, not by workgroup index (see wide_barrier)
@@ -1487,6 +1497,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     int rmin = 1 << 30, rmax = -1, cmin = 1 << 30, cmax = -1;
     int onb = 0;
     if (status_final != SDSM_CAND_ERROR) {
+        __builtin_amdgcn_s_setprio(0);
         for (int p = c.p_lo + opaque_tid(); p < c.p_hi; p += L::WGS) {
             uint32_t rc = c.crop_rc[p];
             int pr = rc >> 16, pc = rc & 0xffffu;
@@ -1500,6 +1511,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
                 cmin = pc < cmin ? pc : cmin; cmax = pc > cmax ? pc : cmax;
             }
         }
+        __builtin_amdgcn_s_setprio(2);
         // 1-px pad ring of the image, polynomial part only (G~ has no rows there)
         const int imH = P.img[cd.image].H, imW = P.img[cd.image].W;
         const int ringw = imW + 2, ringh = imH + 2;
