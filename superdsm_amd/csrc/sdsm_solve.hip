@@ -212,24 +212,48 @@ __device__ __forceinline__ bool wide_barrier(const Cand &c, int phase0)
 }
 
 // All-reduce of up to three LDS (or global) arrays of doubles, in place.  Returns false if the group was given up.
+// Long vectors (the Hessian envelope: ~10 k doubles) as reduce-scatter + all-gather: member g adds the wG partials of ITS share of the
+// entries (in member order, as every member did for all entries before: the same sums bit for bit) and leaves the totals in its own
+// publication block, a second group barrier, then everybody reads the totals -- 2 instead of wG reads per entry and member, for one more
+// barrier.  Short vectors (line-search values, the 28 sums of the elliptical model) keep the single barrier.
+// Publication slots alternate per OPERATION (WIDE_OPS): a member can be at most one operation ahead of the slowest one.
+#define WIDE_OPS (reinterpret_cast<int *>(SD + L::FLAG) + 3)
+#define WIDE_RS_MIN 512
 template <class L>
 __device__ __forceinline__ bool wide_allreduce(const Cand &c, double *a0, int n0, double *a1 = nullptr, int n1 = 0, double *a2 = nullptr, int n2 = 0)
 {
     if (c.wG <= 1) return true;
-    const int phase = *WIDE_PHASE;
-    double *slot = c.wpool + SDSM_WIDE_SYNC + (size_t)(phase & 1) * c.wG * SDSM_WIDE_PBUF;
+    const int phase = *WIDE_PHASE, ops = *WIDE_OPS;
+    double *slot = c.wpool + SDSM_WIDE_SYNC + (size_t)(ops & 1) * c.wG * SDSM_WIDE_PBUF;
     double *mine = slot + (size_t)c.wg * SDSM_WIDE_PBUF;
     const int tid = threadIdx.x;
     for (int e = tid; e < n0; e += L::WGS) mine[e] = a0[e];
     for (int e = tid; e < n1; e += L::WGS) mine[n0 + e] = a1[e];
     for (int e = tid; e < n2; e += L::WGS) mine[n0 + n1 + e] = a2[e];
-    const bool ok = wide_barrier<L>(c, phase);
+    bool ok = wide_barrier<L>(c, phase);
+    if (tid == 0) *WIDE_OPS = ops + 1;                           // (everybody read it before the barrier above)
     const int nt = n0 + n1 + n2;
-    for (int e = tid; e < nt; e += L::WGS) {
-        double v = 0;
-        for (int m = 0; m < c.wG; m++) v += slot[(size_t)m * SDSM_WIDE_PBUF + e];
-        if (!ok) v = NAN;                                        // group given up: every member sees non-finite values and fails the solve
-        if (e < n0) a0[e] = v; else if (e < n0 + n1) a1[e - n0] = v; else a2[e - n0 - n1] = v;
+    if (nt < WIDE_RS_MIN) {
+        for (int e = tid; e < nt; e += L::WGS) {
+            double v = 0;
+            for (int m = 0; m < c.wG; m++) v += slot[(size_t)m * SDSM_WIDE_PBUF + e];
+            if (!ok) v = NAN;                                    // group given up: every member sees non-finite values and fails the solve
+            if (e < n0) a0[e] = v; else if (e < n0 + n1) a1[e - n0] = v; else a2[e - n0 - n1] = v;
+        }
+    } else {
+        const int chunk = (((nt + c.wG - 1) / c.wG) + 7) & ~7;
+        const int lo = c.wg * chunk, hi = lo + chunk < nt ? lo + chunk : nt;
+        for (int e = lo + tid; e < hi; e += L::WGS) {
+            double v = 0;
+            for (int m = 0; m < c.wG; m++) v += slot[(size_t)m * SDSM_WIDE_PBUF + e];
+            mine[e] = v;
+        }
+        ok = wide_barrier<L>(c, phase + 1) && ok;
+        for (int e = tid; e < nt; e += L::WGS) {
+            double v = slot[(size_t)(e / chunk) * SDSM_WIDE_PBUF + e];
+            if (!ok) v = NAN;
+            if (e < n0) a0[e] = v; else if (e < n0 + n1) a1[e - n0] = v; else a2[e - n0 - n1] = v;
+        }
     }
     __syncthreads();
     return ok;
@@ -1360,7 +1384,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
         c.p_lo = wg * chunk < cd.N ? wg * chunk : cd.N;
         c.p_hi = c.p_lo + chunk < cd.N ? c.p_lo + chunk : cd.N;
     }
-    if (tid == 0) *WIDE_PHASE = 0;
+    if (tid == 0) { *WIDE_PHASE = 0; *WIDE_OPS = 0; }
     if (WIDE && wg == 0) {                                               // cleared here: the members set bits at the very end, after many group barriers
         uint32_t *mk0 = masks + cd.mask_off;
         for (int i = tid; i < (cd.h * cd.w + 31) / 32; i += L::WGS) mk0[i] = 0;
@@ -1532,7 +1556,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     onb = -block_min_i32<L::NWAVES>(-onb, ired);
     if (WIDE) {                                                              // bounding box over the members' slices
         const int phase = *WIDE_PHASE;
-        double *slot = c.wpool + SDSM_WIDE_SYNC + (size_t)(phase & 1) * c.wG * SDSM_WIDE_PBUF;
+        double *slot = c.wpool + SDSM_WIDE_SYNC + (size_t)(*WIDE_OPS & 1) * c.wG * SDSM_WIDE_PBUF;
         int *mine = reinterpret_cast<int *>(slot + (size_t)c.wg * SDSM_WIDE_PBUF);
         if (tid == 0) { mine[0] = rmin; mine[1] = cmin; mine[2] = rmax; mine[3] = cmax; }
         const bool okw = wide_barrier<L>(c, phase);

@@ -86,6 +86,10 @@ class CvxprogError(Exception):
 
 DEFAULT_COMPUTING_STATUS_LINE = ('Computing objects', 'Computed objects')
 
+# Batches of fewer candidates than this leave compute units idle even at four candidates per unit: they run in latency mode (256 threads per
+# candidate, the largest regions split over workgroup groups) also when they span several images (lock-step generations of a small image set)
+LATENCY_MODE_BELOW = 1024
+
 # keys of dsm_cfg that only steer the reference's CPU implementation
 _CPU_ONLY_KEYS = ('smooth_mat_max_allocations', 'cachesize', 'cachetest', 'smooth_mat_dtype', 'cp_timeout')
 
@@ -152,7 +156,7 @@ def _solve(images, footprints, image_of, cfg, shard, while_waiting=None):
         assert len(images) == 1, 'sharded batches cover one image'
         return shard.solve(images[0], footprints, cfg)
     batch = engine.Batch(images if len(images) > 1 else images[0], footprints, cfg, image_of=image_of,
-                         mode=1 if len(images) == 1 else 0)        # one image at a time: shortest wall clock; several: fill the GPU
+                         mode=1 if len(images) == 1 or len(footprints) < LATENCY_MODE_BELOW else 0)   # a batch that cannot fill the GPU: shortest wall clock
     batch.launch()
     if while_waiting is not None:                          # host work of the caller while the kernels run (the launch is asynchronous)
         while_waiting()
