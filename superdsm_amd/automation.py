@@ -27,10 +27,12 @@ def normalize_image(img, spread=1):
 
 
 def _integ(ii, r, c, rl, cl):
-    """Clamped box sum on the integral image (rows r .. r + rl, columns c .. c + cl as scikit-image's ``_integ`` takes them)."""
+    """Clamped box sum on the integral image (rows r .. r + rl, columns c .. c + cl as scikit-image's ``_integ`` takes them):
+    the origin is clipped FIRST and the far corner is measured from the clipped origin, so a window that starts above / left of
+    the image slides into it instead of shrinking (parity unpinned, see the module docstring)."""
     H, W = ii.shape
     r1, c1 = np.clip(r, 0, H - 1), np.clip(c, 0, W - 1)
-    r2, c2 = np.clip(r + rl, 0, H - 1), np.clip(c + cl, 0, W - 1)
+    r2, c2 = np.clip(r1 + rl, 0, H - 1), np.clip(c1 + cl, 0, W - 1)
     ans = ii[r1[:, None], c1[None, :]] + ii[r2[:, None], c2[None, :]] - ii[r1[:, None], c2[None, :]] - ii[r2[:, None], c1[None, :]]
     return np.maximum(0, ans)
 

@@ -82,11 +82,26 @@ class RecordGather:
 def _gpu_solve_local(image, footprints, cfg, mask_info):
     """Default local solver of a shard: one engine batch on this rank's GPU.  Returns (records, masks) as uint8 DEVICE tensors
     (nothing is copied to the host here); ``mask_info`` is what every rank expects the shard's mask boxes to be."""
-    from . import engine
+    from . import _capi, engine
     batch = engine.Batch(image, footprints, cfg, latency_mode=True)
     assert np.array_equal(batch.mask_info[:len(footprints)], mask_info), 'plan of the shard disagrees with the replicated layout'
     batch.launch()
     n = len(footprints)
+    if n:
+        # candidates whose workgroup group was given up (a scheduling event on an oversubscribed GPU, SDSM_CAND_GIVEN_UP) are solved
+        # again without groups on the owning rank, before the all-gather -- as objects._solve does for unsharded batches
+        rec32 = batch.records_dev.view(torch.int32).reshape(-1, 32)
+        again = torch.nonzero(rec32[:n, 16] == _capi.CAND_GIVEN_UP).flatten().cpu().numpy()       # (status: int32 #16 of the 128-byte record)
+        if again.size:
+            sub = engine.Batch(image, [footprints[i] for i in again], cfg, mode=2)
+            sub.launch()
+            sub32 = sub.records_dev.view(torch.int32).reshape(-1, 32)
+            for j, i in enumerate(again):
+                rec32[i] = sub32[j]
+                nb = 4 * ((int(batch.mask_info[i, 2]) * int(batch.mask_info[i, 3]) + 31) // 32)
+                o, so = int(batch.mask_offset[i]), int(sub.mask_offset[j])
+                batch.masks_dev[o:o + nb] = sub.masks_dev[so:so + nb]
+            torch.cuda.current_stream().synchronize()                      # (sub's buffers are released on return)
     return batch.records_dev[:n * 128], batch.masks_dev, batch          # (the batch keeps the buffers alive)
 
 

@@ -85,6 +85,9 @@ def process_objects_gpu(objects, g, g_mask_processing, background_mask, exterior
         return np.zeros(0, _capi.POST_RECORD_DTYPE), []
     boxes = np.zeros((n, 4), np.int32)
     words = np.zeros(n, np.int64)
+    if mask_max_distance > 0 and mask_stdamp > 0 and float(mask_max_distance) != int(mask_max_distance):
+        # skimage.morphology.disk(r) of a fractional radius (postprocess.py:316-337) is not a disk of int(r): refuse instead of truncating
+        raise NotImplementedError(f'mask_max_distance = {mask_max_distance!r}: the GPU mask refinement takes integer radii (<= 16) only, see DESIGN.md "Limits"')
     m = int(mask_max_distance) if (mask_max_distance > 0 and mask_stdamp > 0) else 0
     new_words = np.zeros(n, np.int64)
     packed = []
@@ -114,12 +117,12 @@ def process_objects_gpu(objects, g, g_mask_processing, background_mask, exterior
     d_pool = torch.empty(max(1, int(np.where(need_pool, areas, 0).sum())) * 4, dtype=torch.uint8, device=dev)
     d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
     bg = background_mask if torch.is_tensor(background_mask) else to_dev(np.asarray(background_mask, np.uint8))
-    gstd = float(g.std(unbiased=False).item())
+    gstd = float(g.std(unbiased=False).item())               # a constant image: 1 / 0 = inf, the contrast comes out NaN and nothing is discarded, as in the reference (postprocess.py:254-266)
     p = lambda t: C.c_void_p(t.data_ptr())
     with torch.cuda.device(dev):
         _capi.check(L.sdsm_post_objects(p(g), p(g_mask_processing), p(bg), H, W, n, p(d_boxes), p(d_bits_off), p(d_bits), p(d_new_off), p(d_new),
                                         p(d_pool), p(d_bpool_off), float(exterior_scale), float(exterior_offset), float(contrast_epsilon),
-                                        1.0 / gstd, m, float(mask_stdamp), p(d_out), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                        (1.0 / gstd) if gstd > 0 else float('inf'), m, float(mask_stdamp), p(d_out), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                     'sdsm_post_objects')
         recs = d_out.cpu().numpy().view(_capi.POST_RECORD_DTYPE).copy()
         new_bits = d_new.cpu().numpy() if m > 0 else None

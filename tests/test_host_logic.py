@@ -337,3 +337,20 @@ def test_native_search_space_count_equals_the_enumeration(workload):
         with pytest.raises(ValueError):
             globalenergymin._remaining_by_cluster([atoms], adj, np.inf, max_amount=total - 1, skip_last=True)
         globalenergymin._remaining_by_cluster([atoms], adj, np.inf, max_amount=total, skip_last=True)
+
+
+def test_integral_box_slides_at_the_top_left_border():
+    """scikit-image's ``_integ`` (used by the determinant-of-Hessian blobs, automation.py:13-38) clips the window's origin first and
+    measures the far corner from the CLIPPED origin: a window that starts above / left of the image keeps its size and slides in.
+    Hand-computed on a 6x6 image of ones (integral image ii[r, c] = (r + 1)(c + 1)); parity with scikit-image itself is unpinned
+    (not importable here)."""
+    ii = np.ones((6, 6)).cumsum(0).cumsum(1)
+    r = np.array([-2, 0, 3, 5])
+    c = np.array([-1, 2])
+    got = automation._integ(ii, r, c, 2, 3)
+    # rows: origin clipped to (0, 0, 3, 5), far row min(origin + 2, 5) = (2, 2, 5, 5) -> heights 2, 2, 2, 0
+    # columns: origin (0, 2), far column min(origin + 3, 5) = (3, 5) -> widths 3, 3
+    want = np.array([[2 * 3, 2 * 3], [2 * 3, 2 * 3], [2 * 3, 2 * 3], [0, 0]], float)
+    assert np.array_equal(got, want)
+    # the unclipped-origin variant would shrink the first window to 0 rows (far row = -2 + 2 = 0)
+    assert got[0, 0] == 6.0
