@@ -88,7 +88,6 @@ def lib():
         L.orc_compute_objects.restype = vp
         L.orc_set_inner_threads.argtypes = [i32]
         L.orc_set_exact_hessian.argtypes = [i32]
-        L.orc_set_hess_subsample.argtypes = [i32]
         L.orc_batch_free.argtypes = [vp]
         L.orc_batch_records.argtypes = [vp]
         L.orc_batch_records.restype = vp
