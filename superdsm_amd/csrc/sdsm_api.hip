@@ -122,7 +122,7 @@ struct sdsm_plan {
     int n = 0;
     std::vector<PlanImage> images;             // one entry for sdsm_plan_create, several for sdsm_plan_create_multi
     sdsm_dsm_config cfg{};
-    int k = 1, R = 0, zcap = 1, no_deform = 0;
+    int k = 1, R = 0, zcap = 1, zcap_run = 1, zshift = 0, no_deform = 0;
     std::vector<CandDesc> cand;
     std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those whose bound on M admits more than solve class 1, then more than class 2
     int n_order_c = 0, n_order_d = 0, n_order_w = 0;   // the last list: (candidate | member << 24) of the workgroup groups
@@ -132,9 +132,9 @@ struct sdsm_plan {
     std::vector<float> psf;
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
-    int64_t total_pixels = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0, n_wide = 0;
-    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_ell_meta = 0,
-           off_grid = 0, off_ell_idx = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, off_ticket = 0, total = 0;
+    int64_t total_pixels = 0, total_runs = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0, n_wide = 0;
+    size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_run_meta = 0,
+           off_run_q0 = 0, off_run_aux = 0, off_grid = 0, off_ell_im = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, off_ticket = 0, total = 0;
     // The launch lists and CandDesc.wide_* live in the workspace (sdsm_batch_upload): a layout change after the upload
     // (sdsm_plan_set_latency_mode) would leave stale tables on the device, so launches check the generation they were uploaded at.
     uint64_t layout_gen = 0;
@@ -252,18 +252,20 @@ static void layout_plan(sdsm_plan *p)
     p->off_fp = take(4 * std::max<size_t>(p->fp_labels.size(), 1));
     p->off_order = take(4 * std::max<size_t>(p->order.size(), 1));
     p->off_psf = take(4 * p->psf.size());
-    size_t np = (size_t)std::max<int64_t>(p->total_pixels, 1);
-    p->off_crop_y = take(8 * np);
-    p->off_crop_rc = take(4 * np);
+    size_t np = (size_t)std::max<int64_t>(p->total_pixels, 1), nr = (size_t)std::max<int64_t>(p->total_runs, 1);
+    p->off_crop_y = take(8 * SDSM_RUN * nr);
+    p->off_crop_rc = take(4 * nr);
+    p->off_run_meta = take(4 * nr);
+    p->off_run_q0 = take(4 * nr);
+    p->off_run_aux = take(4 * nr);
     p->off_crop_cc = take(4 * np);
     p->off_dist = take(4 * np);
     p->off_tmp_y = take(8 * np);
     p->off_tmp_rc = take(4 * np);
     p->off_inv = take(4 * np);
-    p->off_ell_meta = take(4 * np);
     p->off_grid = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
-    p->off_ell_idx = take(2 * (size_t)std::max<int64_t>(p->total_ell, 1));
-    p->off_ell_w = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
+    p->off_ell_im = take(4 * (size_t)std::max<int64_t>(p->total_ell, 1));
+    p->off_ell_w = take(16 * (size_t)std::max<int64_t>(p->total_ell, 1));
     p->off_env_fst = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1));      // n_hglob counts doubles
@@ -296,8 +298,13 @@ extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, con
         p->R = p->k / 2;
         long per = (2 * p->R) / cfg->smooth_subsample + 1;
         long z = per * per;
-        p->zcap = (int)std::min<long>((z + 3) / 4 * 4, 4 * SDSM_MAX_ELL_GROUPS);   // groups of 4 entries; a solvable row has <= M <= 1018 entries
-    } else { p->psf.assign(1, 1.f); p->k = 1; p->R = 0; p->zcap = 4; }
+        p->zcap = (int)std::min<long>(z, 4 * SDSM_MAX_ELL_GROUPS);   // grid points are at least `subsample` apart (chessboard): at most per^2 inside a pixel's window; a solvable row has <= M <= 1018 entries
+        // a run spans up to SDSM_RUN columns: the union of its pixels' windows is SDSM_RUN - 1 columns wider
+        const long per_c = (2 * p->R + SDSM_RUN - 1) / cfg->smooth_subsample + 1;
+        p->zcap_run = (int)std::min<long>(per * per_c, 4 * SDSM_MAX_ELL_GROUPS);
+        p->zshift = p->zcap_run > SDSM_MAX_ELL_GROUPS ? 2 : 0;
+        if (p->zshift) p->zcap_run = (p->zcap_run + 3) / 4 * 4;                   // sort classes of 4 entries: rows are padded to whole classes
+    } else { p->psf.assign(1, 1.f); p->k = 1; p->R = 0; p->zcap = 1; p->zcap_run = 1; p->zshift = 0; }
     const int s = cfg->smooth_subsample;
     p->cand.resize(n); p->mask_info.resize((size_t)4 * n); p->mask_off_bytes.resize(n); p->xi_off.resize(n); p->n_pixels.resize(n);
     p->fp_labels.assign(labels, labels + (n > 0 ? offsets[n] : 0));
@@ -316,13 +323,17 @@ extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, con
             r0 = std::min(r0, st[1]); r1 = std::max(r1, st[2]); c0 = std::min(c0, st[3]); c1 = std::max(c1, st[4]);
         }
         if (r1 < 0) { r0 = c0 = 0; r1 = c1 = 0; N = 0; }
-        c.image = im; c.pad0 = 0;
+        c.image = im; c.pad1 = 0;
         c.N = (int32_t)N; c.r0 = r0; c.c0 = c0; c.h = r1 - r0 + 1; c.w = c1 - c0 + 1;
         c.fp_off = offsets[i]; c.fp_len = offsets[i + 1] - offsets[i];
         long mc = p->no_deform ? 1 : (long)((c.h + s - 1) / s) * ((c.w + s - 1) / s);
         c.Mcap = (int32_t)std::max<long>(1, std::min<long>(mc, std::max<long>(N, 1)));
+        // runs: the region pixels of one image row inside one aligned 4-column cell; at most one per pixel and one per cell of the bounding box
+        const long ncw = c.w > 0 ? ((c0 + c.w - 1) >> 2) - (c0 >> 2) + 1 : 1;
+        c.NRcap = (int32_t)std::max<long>(1, std::min<long>(N, (long)c.h * ncw));
         c.crop_off = p->total_pixels; p->total_pixels += N;
-        c.ell_off = p->total_ell; p->total_ell += (int64_t)N * p->zcap;
+        c.run_off = p->total_runs; p->total_runs += c.NRcap;
+        c.ell_off = p->total_ell; p->total_ell += (int64_t)c.NRcap * p->zcap_run;
         c.xi_off = p->total_xi; p->total_xi += c.Mcap;
         c.mask_off = p->total_mask_words; p->total_mask_words += ((int64_t)c.h * c.w + 31) / 32;
         if (6 + c.Mcap > SDSM_ENV_DENSE_N) {
@@ -392,8 +403,8 @@ extern "C" int sdsm_plan_layout(const sdsm_plan *p, int64_t *out)
 {
     if (!p || !out) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_layout: null argument");
     int64_t v[16] = {(int64_t)p->off_cand, (int64_t)p->off_state, (int64_t)p->off_crop_y, (int64_t)p->off_crop_rc, (int64_t)p->off_crop_cc,
-                     (int64_t)p->off_ell_meta, (int64_t)p->off_grid, (int64_t)p->off_ell_idx, (int64_t)p->off_ell_w, p->zcap, p->k,
-                     (int64_t)sizeof(CandDesc), p->total_pixels, p->total_ell, (int64_t)sizeof(CandState), 0};
+                     (int64_t)p->off_run_meta, (int64_t)p->off_grid, (int64_t)p->off_ell_im, (int64_t)p->off_ell_w, p->zcap_run, p->k,
+                     (int64_t)sizeof(CandDesc), p->total_pixels, p->total_ell, (int64_t)sizeof(CandState), p->total_runs};
     memcpy(out, v, sizeof(v));
     return SDSM_OK;
 }
@@ -432,14 +443,15 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
     BatchParams P{};
     P.n = p->n; P.n_images = (int)p->images.size();
     for (size_t i = 0; i < p->images.size(); i++) { P.img[i].H = p->images[i].H; P.img[i].W = p->images[i].W; }   // device pointers: filled by the launch
-    P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
+    P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.zcap_run = p->zcap_run; P.zshift = p->zshift; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
     P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels;
     P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
     P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);
     P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);
     P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);
     P.dist = (uint32_t *)(b + p->off_dist); P.grid_rc = (uint32_t *)(b + p->off_grid);
-    P.ell_idx = (uint16_t *)(b + p->off_ell_idx); P.ell_w = (float *)(b + p->off_ell_w); P.ell_meta = (uint32_t *)(b + p->off_ell_meta);
+    P.ell_im = (uint32_t *)(b + p->off_ell_im); P.ell_w = (float *)(b + p->off_ell_w); P.run_meta = (uint32_t *)(b + p->off_run_meta);
+    P.run_q0 = (uint32_t *)(b + p->off_run_q0); P.run_aux = (uint32_t *)(b + p->off_run_aux);
     P.tmp_y = (double *)(b + p->off_tmp_y); P.tmp_rc = (uint32_t *)(b + p->off_tmp_rc); P.inv = (uint32_t *)(b + p->off_inv);
     P.hess_thr = SDSM_HESS_THR;
     P.psf = (const float *)(b + p->off_psf);

@@ -28,21 +28,25 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_K1_EMAX 2560
 #define SDSM_K1B_NMAX 256          // solve class 1b: 6 + M <= 256 and envelope <= 6144 doubles: 256 threads, LDS ~ 68 KB, TWO workgroups per compute unit
 #define SDSM_K1B_EMAX 6144         //   (between class 1 and class 2, whose 157 KB leave one workgroup per compute unit: regions of ~5-15 k pixels, M ~ 100-250)
-#define SDSM_K2B_NMAX 512          // solve class 2b: 6 + M <= 512 and envelope <= 15900 doubles: the LDS that class 2 spends on vectors of 1024 unknowns
-#define SDSM_K2B_EMAX 15900        //   holds a larger envelope instead (~ 160 KB): keeps most of what class 2 cannot hold out of the global-memory class
+#define SDSM_K2B_NMAX 512          // solve class 2b: 6 + M <= 512 and envelope <= 15200 doubles: the LDS that class 2 spends on vectors of 1024 unknowns
+#define SDSM_K2B_EMAX 15200        //   holds a larger envelope instead (~ 160 KB): keeps most of what class 2 cannot hold out of the global-memory class
 // Very large regions are solved by a GROUP of workgroups (2 .. 8, one per 8192 pixels): each takes a slice of the pixels in
 // every pass and the partial sums / gradient / Hessian are all-reduced through global memory (sdsm_solve.hip, WIDE).
 #define SDSM_WIDE_MIN_PIXELS 12288
 #define SDSM_WIDE_SLICE 8192
 #define SDSM_WIDE_MAX_G 8
 #define SDSM_WIDE_SYNC 16           // doubles reserved for the group's counters at the start of its pool block
-#define SDSM_WIDE_PBUF (SDSM_K2_EMAX + SDSM_MAX_N_SOLVE + 64)   // doubles one workgroup publishes per all-reduce
+#define SDSM_WIDE_FCAP 4104         // of them for the psi-type sums of the member's super-chunks (1 count + 4 * 1024 + pad: slices of up to 2 M pixels)
+#define SDSM_WIDE_PBUF (SDSM_K2_EMAX + SDSM_MAX_N_SOLVE + 64 + SDSM_WIDE_FCAP)   // doubles one workgroup publishes per exchange
 #define SDSM_WIDE_PIXELS 3072       // latency mode: larger regions go to class 2 (512 threads per candidate; a batch is as slow as its slowest candidate)
-#define SDSM_K2_EMAX 11000         // solve class 2: 6 + M <= SDSM_MAX_N_SOLVE and envelope <= 11000 doubles (LDS ~ 157 KB)
+#define SDSM_K2_EMAX 10300         // solve class 2: 6 + M <= SDSM_MAX_N_SOLVE and envelope <= 10300 doubles (LDS ~ 157 KB)
 #define SDSM_K1_DENSE_N 70         // 6 + M <= 70: even a dense triangle fits class 1
-#define SDSM_ENV_DENSE_N 146       // 6 + M <= 146: even a dense triangle fits class 2
-#define SDSM_ELL_GROUPS_REG 7       // groups of 4 G~ row entries the solve kernel keeps in registers (rows of <= 28 entries)
-#define SDSM_MAX_ELL_GROUPS 256    // zcap <= 1024 entries per row of G~ (a solvable candidate has M <= 1018 columns)
+#define SDSM_ENV_DENSE_N 142       // 6 + M <= 142: even a dense triangle fits class 2
+#define SDSM_RUN 4                  // pixels per run: the region pixels of one image row inside one aligned 4-column cell share a G~ index list
+#define SDSM_MAX_ELL_GROUPS 256    // classes of the counting sort of the runs by their number of G~ entries (zcap_run <= 1024: classes of 4 beyond 256)
+#define SDSM_HZREG 8                // leading ('significant') entries of a run the solve kernel keeps in registers for the approximate Hessian
+#define SDSM_MSLOTS 32              // lane slots (lane & 31) of the fixed-point moment accumulators in LDS
+#define SDSM_SUPER 8                // chunks (of 64 runs) per super-chunk: psi = sequential sum over super-chunks of the sequential sum of their chunk totals
 #ifndef SDSM_PANEL
 #define SDSM_PANEL 4               // columns per panel (8 measured slower: 195 k vs 200 k solves/s); of the envelope Cholesky; first stored columns are multiples of it
 #endif
@@ -60,8 +64,8 @@ enum { ST_OK = 0, ST_TRIVIAL = 2, ST_ERROR = 3, ST_UNSUPPORTED = 4 };
 
 // Host-planned description of one candidate (read-only on the device).
 struct CandDesc {
-    int64_t crop_off;   // first pixel of the candidate's packed crop (crop_y / crop_rc / crop_cc / ell_meta)
-    int64_t ell_off;    // first entry of its ELL block (N * zcap4 entries: groups of 4 slots, group-major)
+    int64_t crop_off;   // first pixel of the candidate's per-pixel setup arrays (tmp_y / tmp_rc / crop_cc / dist / inv)
+    int64_t ell_off;    // first entry of its G~ block (NRcap * zcap_run entries; entry j of run position p at j * NR + p)
     int64_t mask_off;   // first uint32 word of its bit-packed region-bbox mask
     int64_t xi_off;     // first entry of its grid / xi block (Mcap entries)
     int32_t N;          // region pixels (sum of the atoms' valid areas)
@@ -73,7 +77,9 @@ struct CandDesc {
     int64_t hglob_off;  // first double of its block in the global Hessian pool (a dense triangle of 6 + min(Mcap, 1018) unknowns; only if 6 + Mcap > SDSM_ENV_DENSE_N: the envelope may not fit LDS), else -1
     int64_t wide_off;   // first double of the group's block in the wide pool: SDSM_WIDE_SYNC + 2 * wide_g * SDSM_WIDE_PBUF doubles; else -1
     int32_t image;      // index into BatchParams.img (plans over several images, sdsm_plan_create_multi)
-    int32_t pad0;
+    int32_t NRcap;      // upper bound of the number of runs (min(N, rows * 4-column cells of the bounding box))
+    int64_t run_off;    // first run of the candidate's packed crop (crop_y: 4 doubles per run; crop_rc, run_meta, run_q0, run_aux: one word per run)
+    int64_t pad1;
 };
 
 // Written by the setup kernel.
@@ -82,16 +88,17 @@ struct CandState {
     int32_t status;     // ST_*
     int32_t hc, wc;     // shape of the mask after deleting empty rows / columns (dsm.py:185-186)
     int32_t npos;       // region pixels with y > 0
-    int32_t zmax;       // largest number of non-zeros in a row of G~
+    int32_t zmax;       // largest number of G~ entries of a run (union of the rows of its pixels)
     unsigned long long sum_r, sum_c, sum_rr, sum_cc;   // moments of the y > 0 pixels (image coordinates)
-    int32_t hzmax;      // largest number of 'significant' entries (>= hess_thr * row maximum) in a row of G~
+    int32_t hzmax;      // largest number of leading entries of a run ('significant', >= hess_thr * row maximum, for at least one of its pixels)
     int32_t env_size;   // doubles of the solver's Hessian in envelope storage (see env_fst / env_rb)
     int32_t nneg;       // region pixels with y < 0
     int32_t yexp;       // |y| < 2^yexp for every region pixel (clamped to +-400): scale of the solver's fixed-point sums
-    int32_t gcount[8];  // gcount[j] = crop positions whose row has more than 4 j entries (positions are sorted by that)
+    int32_t NR;         // runs of the packed crop
+    int32_t pad[7];
 };
-static_assert(sizeof(CandState) == 104 && SDSM_ELL_GROUPS_REG <= 8, "CandState layout");
-static_assert(sizeof(CandDesc) == 96, "CandDesc layout");
+static_assert(sizeof(CandState) == 104, "CandState layout");
+static_assert(sizeof(CandDesc) == 112, "CandDesc layout");
 
 // One image of a plan: device pointers given at launch time, shape from the plan.
 #define SDSM_MAX_IMAGES 16
@@ -105,7 +112,8 @@ struct ImageRef {
 struct BatchParams {
     int32_t n, n_images;
     ImageRef img[SDSM_MAX_IMAGES];
-    int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, ELL slots per pixel (a multiple of 4)
+    int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, bound on the entries of one pixel's row of G~
+    int32_t zcap_run, zshift;          // bound on the entries of a run (union of <= 4 rows); sort class of a run = (entries + (1 << zshift) - 1) >> zshift
     int32_t no_deform;                 // smooth_amount == inf
     int32_t no_trivial_rule;           // sdsm_dsm_config.flags bit 0: solve even a region with a single positive pixel (cvxprog called directly, c2freganal.py:58-79)
     int32_t init_elliptical, max_iters;
@@ -116,20 +124,27 @@ struct BatchParams {
     CandState *state;
     const int32_t *fp_labels;
     const int32_t *order;              // workgroup -> candidate (largest first)
-    double *crop_y;                    // 8 B / pixel, final crop order (rows with the most G~ entries first)
-    uint32_t *crop_rc;                 // (row << 16) | col, image coordinates: 4 B / pixel, final crop order
-    double *tmp_y;                     // setup only: the crop in scan order (low-discrepancy scatter of the raster rank)
-    uint32_t *tmp_rc;                  // setup only
-    uint32_t *crop_cc;                 // compressed coordinates (setup only, scan order)
-    uint32_t *dist;                    // setup only: chessboard distance to the nearest grid point, then the final crop position
-    uint32_t *inv;                     // setup only: scan-order index of a final crop position
+    // Packed crop, by RUN: the region pixels of one image row inside one aligned 4-column cell (1 .. 4 pixels) are one run; they
+    // share u, the list of grid points around them and (to a large extent) the leading entries of their rows, so a lane of the
+    // solve kernel that owns a run adds ONE fixed-point sum per gradient / Hessian entry for up to four pixels.  Final order: a
+    // low-discrepancy scatter of the raster order of the runs, stably sorted by their number of G~ entries, longest first.
+    double *crop_y;                    // 4 doubles per run (absent pixels 0): 8 B / pixel
+    uint32_t *crop_rc;                 // (row << 16) | first column of the cell, image coordinates
+    uint32_t *run_meta;                // entries | leading entries << 12 | present pixels (4 bits) << 24
+    uint32_t *run_q0;                  // setup only, raster order of the runs: raster rank of the run's first pixel | present pixels << 28
+    uint32_t *run_aux;                 // setup only: [chunk of 64 positions] entries of the chunk's first run (padding target of its rows)
+    double *tmp_y;                     // setup only, per pixel: the crop in scan order (low-discrepancy scatter of the raster rank)
+    uint32_t *tmp_rc;                  // setup only, per pixel
+    uint32_t *crop_cc;                 // setup only, per pixel: compressed coordinates (scan order)
+    uint32_t *dist;                    // setup only, per pixel: chessboard distance to the nearest grid point; then, per run (scan order of the runs): entries
+    uint32_t *inv;                     // setup only, per run (scan order of the runs): final position
     uint32_t *grid_rc;                 // sorted grid points, compressed coordinates
-    // G~ rows: entry s of the row of crop position p is element ((s / 4) * N + p) * 4 + s % 4 of the candidate's block:
-    // one 16-byte (weights) + one 8-byte (column indices) load per lane fetches 4 entries, consecutive lanes read
-    // consecutive addresses
+    // G~ of a run: entry j of run position p is element j * NR + p of the candidate's block: one 16-byte load (the weights of the
+    // run's four pixels for that grid point, float32 as the reference builds them, 0 where the point is outside a pixel's window)
+    // and one 4-byte load (column index | pixels for which the entry is a leading one << 16) per lane; consecutive lanes read
+    // consecutive addresses.  Leading entries first, in ascending column order.
     float *ell_w;
-    uint16_t *ell_idx;
-    uint32_t *ell_meta;                // entries of the row | entries used by the solver's approximate Hessian << 16
+    uint32_t *ell_im;
     // Envelope of the solver's Hessian, unknowns ordered xi_0 .. xi_{M-1}, theta_0 .. theta_5: row a of the xi block
     // stores columns env_fst[a] .. a (env_fst: smallest column any pixel couples a with, made non-decreasing in a and a
     // multiple of SDSM_PANEL), entry (a, b) at env_rb[a] + b; the 6 theta rows are dense and follow.  Indexed by xi_off + a.
@@ -285,6 +300,25 @@ __device__ __forceinline__ void block_excl_count4(const bool (&flag)[4], int *sc
         run += tot;
     }
     *total = run;
+}
+
+// Exclusive prefix sum of small unsigned values over the workgroup in thread order (Hillis-Steele inside a wavefront, one LDS
+// hop across the wavefronts); *total = sum over the workgroup.  scratch: WAVES unsigned.
+template <int WAVES = SDSM_WAVES>
+__device__ __forceinline__ unsigned block_excl_scan_u32(unsigned v, unsigned *scratch, unsigned *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    __syncthreads();                                   // scratch may still be read by the previous user
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    unsigned before = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; i++) { const unsigned c = scratch[i]; if (i < wave) before += c; tot += c; }
+    *total = tot;
+    return before + inc - v;
 }
 
 // Exclusive prefix count of `flag` over the workgroup in thread order; *total = number of set flags.

@@ -1,6 +1,7 @@
-// Candidate setup: region crop, compressed coordinates, greedy sub-sample grid, G~ rows (ELL, 4 entries per group,
-// crop positions sorted by the number of groups of their row).
-// One 256-thread workgroup per candidate.
+// Candidate setup: region crop packed by RUNS (the region pixels of one image row inside one aligned 4-column cell), compressed
+// coordinates, greedy sub-sample grid, G~ of the runs (one entry = a grid point with the weights of the run's four pixels; run
+// positions sorted by their number of entries).
+// One 256- or 1024-thread workgroup per candidate.
 //
 // Reference behaviour restated here (never its code):
 //   region        superdsm/objects.py:93,126-127  in1d(atoms, footprint) & y_mask & (EDT(y<=0) <= margin)
@@ -22,9 +23,6 @@ struct WeightCtx {
     int nnz;                // entries of the row (grid points inside the PSF window)
     float wmax;             // largest of them
 };
-
-// entry s of the row whose group-0 element starts at base (= ell_off + 4 * position)
-__device__ __forceinline__ int64_t ell_at(int64_t base, int N, int s) { return base + (int64_t)(s >> 2) * N * 4 + (s & 3); }
 
 __device__ __forceinline__ float wval(WeightCtx &c, int j)
 {
@@ -95,87 +93,157 @@ __device__ __forceinline__ int cheb(int r0, int c0, int r1, int c1)
     return a > b ? a : b;
 }
 
-// Rows of G~ for the raster ranks [q0, q1) of a candidate: PSF gather, float32 pairwise row sum, float32 division
-// (dsm.py:192-193), entries written once into their final slots.  Pixels are taken in RASTER order (rank q -> scan index
-// q * perm_inv mod N): the 64 lanes of a wavefront then sit next to each other in the image, see (almost) the same grid
-// points and take the same branches in the loops over them; in crop order they are scattered and every lane's hits are
-// paid for by all (measured 3x on 73 k-pixel regions).  efirst (LDS, M ints, initialised to j): first coupled column.
-__device__ __forceinline__ void rows_of_ranks(const BatchParams &P, const CandDesc &cd, int M, int R, int hc, const uint32_t *gridkeys,
-                                              const uint16_t *growstart, const float *psf_lds, int *efirst, int q0, int q1, int step,
-                                              bool &bad, int &hzmax)
+// Multiplier of the low-discrepancy scatter of the runs: scan index of raster run rr = (rr * B) mod NR, B ~ 0.618 NR coprime to NR
+// (neighbouring positions are far apart in the image, which decorrelates the LDS atomics of the solve kernel).
+__device__ __forceinline__ uint32_t scatter_mult(uint32_t NR)
 {
-    for (int q = q0; q < q1; q += step) {
-        const int i = (int)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N);
-        const int pos = (int)P.dist[cd.crop_off + i];
-        uint32_t key = P.crop_cc[cd.crop_off + i];
-        // pass 1 over the grid points: row sum in numpy's order, largest entry, number of entries (nothing is stored)
-        WeightCtx c;
-        c.cr = key >> 16; c.cc = key & 0xffffu; c.R = R; c.k = P.k; c.psf = P.psf; c.psf_lds = psf_lds; c.keys = gridkeys; c.nnz = 0; c.wmax = 0.f;
-        c.jlo = growstart[c.cr - R > 0 ? c.cr - R : 0]; c.jhi = c.cr + R + 1 < hc ? growstart[c.cr + R + 1] : M;
-        const int64_t base = cd.ell_off + (int64_t)pos * 4;
-        P.crop_y[cd.crop_off + pos] = P.tmp_y[cd.crop_off + i];
-        P.crop_rc[cd.crop_off + pos] = P.tmp_rc[cd.crop_off + i];
-        const float sum = pw_sum(c, M);
-        if (c.nnz > P.zcap || !(sum > 0.f)) { bad = true; P.ell_meta[cd.crop_off + pos] = 0; continue; }   // dsm.py:194
-        // pass 2: normalised entries written once, straight into their final slots: entries >= hess_thr * row maximum (the
-        // solver's approximate Hessian uses only those; S and the gradient use all) from slot 0 upwards -- in ascending
-        // column order, so the solve kernel knows which of a pair is the row --, the others from slot nnz - 1 downwards
-        const float lim = P.hess_thr * __fdiv_rn(c.wmax, sum);
-        int hz = 0, others = 0, mn = 0;
-        // The entries leave as whole 4-entry groups (one 16-byte store of weights + one 8-byte store of column indices, what the
-        // solve kernel loads), not as 2- and 4-byte stores scattered over the groups: the leading entries fill a register buffer
-        // upwards from slot 0, the others a second one downwards from slot nnz - 1; a buffer is stored when its group is complete,
-        // the group in which the two meet at the end.
-        float fw[4] = {0.f, 0.f, 0.f, 0.f}, bw[4] = {0.f, 0.f, 0.f, 0.f};
-        int fi[4] = {0, 0, 0, 0}, bi[4] = {0, 0, 0, 0};
-        auto store_group = [&](int g, const float (&w4)[4], const int (&i4)[4]) {
-            const int64_t e = ell_at(base, cd.N, 4 * g);
-            f32x4 wv; wv.x = w4[0]; wv.y = w4[1]; wv.z = w4[2]; wv.w = w4[3];
-            *reinterpret_cast<f32x4 *>(P.ell_w + e) = wv;
-            uint2 iv; iv.x = (uint32_t)i4[0] | ((uint32_t)i4[1] << 16); iv.y = (uint32_t)i4[2] | ((uint32_t)i4[3] << 16);
-            *reinterpret_cast<uint2 *>(P.ell_idx + e) = iv;
-        };
-        for (int j = c.jlo; j < c.jhi; j++) {
-            const uint32_t gk = gridkeys[j];
-            int dr = (int)(gk >> 16) - c.cr, dc = (int)(gk & 0xffffu) - c.cc;
-            const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
-            if (adr > R || adc > R) continue;
-            const int pidx = (R + dr) * P.k + (R + dc);
-            const float nw = __fdiv_rn(psf_lds ? psf_lds[pidx] : P.psf[pidx], sum);
-            if (!(nw < lim)) {
-                // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
-                if (hz == 0) mn = j; else atomicMin(&efirst[j], mn);
-                const int l = hz & 3;
+    if (NR <= 2) return 1;
+    uint32_t B = (uint32_t)(0.6180339887498949 * (double)NR);
+    if (B < 1) B = 1;
+    for (;;) {
+        uint32_t a = B, b = NR;
+        while (b) { const uint32_t t = a % b; a = b; b = t; }
+        if (a == 1) return B;
+        B++;
+    }
+}
+
+// The pixels of raster run rr: present mask, scan indices (into the per-pixel setup arrays) of the present ones.
+struct RunPixels { uint32_t mask; int idx[SDSM_RUN]; };
+__device__ __forceinline__ RunPixels run_pixels(const BatchParams &P, const CandDesc &cd, int rr)
+{
+    RunPixels rp;
+    const uint32_t q0m = P.run_q0[cd.run_off + rr];
+    rp.mask = q0m >> 28;
+    uint32_t q = q0m & 0x0fffffffu;
 #pragma unroll
-                for (int t = 0; t < 4; t++) { fw[t] = l == t ? nw : fw[t]; fi[t] = l == t ? j : fi[t]; }
-                hz++;
-                if ((hz & 3) == 0) store_group((hz >> 2) - 1, fw, fi);
-            } else {
-                const int slot = c.nnz - 1 - others++;
-                const int l = slot & 3;
+    for (int k = 0; k < SDSM_RUN; k++) {
+        rp.idx[k] = -1;
+        if ((rp.mask >> k) & 1u) { rp.idx[k] = (int)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N); q++; }
+    }
+    return rp;
+}
+
+// Runs without G~ (null matrix, or more grid points than the solver holds): the final order is the scan order of the runs.
+__device__ __forceinline__ void plain_runs(const BatchParams &P, const CandDesc &cd, int NR, uint32_t B, int tid, int nthreads)
+{
+    for (int rr = tid; rr < NR; rr += nthreads) {
+        const int pos = (int)(((unsigned long long)rr * B) % (unsigned long long)NR);
+        const RunPixels rp = run_pixels(P, cd, rr);
+        double yk[SDSM_RUN];
+        uint32_t rc0 = 0;
+        bool first = true;
 #pragma unroll
-                for (int t = 0; t < 4; t++) { bw[t] = l == t ? nw : bw[t]; bi[t] = l == t ? j : bi[t]; }
-                if (l == 0) store_group(slot >> 2, bw, bi);
+        for (int k = 0; k < SDSM_RUN; k++) {
+            yk[k] = 0;
+            if (rp.idx[k] >= 0) {
+                yk[k] = P.tmp_y[cd.crop_off + rp.idx[k]];
+                if (first) { rc0 = P.tmp_rc[cd.crop_off + rp.idx[k]] - (uint32_t)k; first = false; }
             }
         }
-        if (hz & 3) {                                    // the group where the two runs meet (or where the leading entries end)
-            const int l = hz & 3;
-            // lanes below l from the leading run; lanes from l on from the other run, whose buffer holds this group if there are
-            // others at all (their lowest slot is hz), else zeros
-            const bool back_here = others > 0;
+        double *yo = P.crop_y + (cd.run_off + pos) * SDSM_RUN;
 #pragma unroll
-            for (int t = 0; t < 4; t++) if (t >= l) { fw[t] = back_here ? bw[t] : 0.f; fi[t] = back_here ? bi[t] : 0; }
-            store_group(hz >> 2, fw, fi);
+        for (int k = 0; k < SDSM_RUN; k++) yo[k] = yk[k];
+        P.crop_rc[cd.run_off + pos] = rc0;
+        P.run_meta[cd.run_off + pos] = rp.mask << 24;
+    }
+}
+
+// G~ of the raster runs [rr0, rr1) of a candidate: per pixel the PSF gather, numpy's pairwise float32 row sum and the float32
+// division (dsm.py:192-193), exactly as the reference builds the pixel's row; per run ONE pass over the grid points of the rows
+// within R that writes an entry for every point inside the window of at least one of its pixels (weight 0 for the others).
+// Runs are taken in RASTER order: the 64 lanes of a wavefront then sit next to each other in the image, see (almost) the same
+// grid points and take the same branches in the loops over them.  efirst (LDS, M ints, initialised to j): first coupled column.
+__device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDesc &cd, int NR, uint32_t B, int M, int R, int hc, const uint32_t *gridkeys,
+                                             const uint16_t *growstart, const float *psf_lds, int *efirst, int rr0, int rr1, int step,
+                                             bool &bad, int &hzmax)
+{
+    for (int rr = rr0; rr < rr1; rr += step) {
+        const int si = (int)(((unsigned long long)rr * B) % (unsigned long long)NR);
+        const int pos = (int)P.inv[cd.crop_off + si];
+        const int nnz = (int)P.dist[cd.crop_off + si];
+        const RunPixels rp = run_pixels(P, cd, rr);
+        int cr = 0, cck[SDSM_RUN];
+        double yk[SDSM_RUN];
+        uint32_t rc0 = 0;
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < SDSM_RUN; k++) {
+            yk[k] = 0; cck[k] = -(1 << 20);              // an absent pixel: no grid point is inside its window
+            if (rp.idx[k] >= 0) {
+                yk[k] = P.tmp_y[cd.crop_off + rp.idx[k]];
+                const uint32_t key = P.crop_cc[cd.crop_off + rp.idx[k]];
+                cr = key >> 16; cck[k] = key & 0xffffu;
+                if (first) { rc0 = P.tmp_rc[cd.crop_off + rp.idx[k]] - (uint32_t)k; first = false; }
+            }
         }
-        // padding (index 0, weight 0) up to the group count of the first position of this pixel's 64-position chunk (a
-        // wavefront of the solve kernel reads the groups its first lane needs for all of its lanes): P.inv[chunk]
-        const int kh = (int)P.inv[cd.crop_off + (pos >> 6)];
+        double *yo = P.crop_y + (cd.run_off + pos) * SDSM_RUN;
+#pragma unroll
+        for (int k = 0; k < SDSM_RUN; k++) yo[k] = yk[k];
+        P.crop_rc[cd.run_off + pos] = rc0;
+        // pass 1, per pixel: row sum in numpy's order, largest entry, number of entries (nothing is stored)
+        const int jlo = growstart[cr - R > 0 ? cr - R : 0], jhi = cr + R + 1 < hc ? growstart[cr + R + 1] : M;
+        float sumk[SDSM_RUN], limk[SDSM_RUN];
+        bool rowbad = nnz > P.zcap_run;
+#pragma unroll
+        for (int k = 0; k < SDSM_RUN; k++) {
+            sumk[k] = 1.f; limk[k] = 0.f;
+            if (rp.idx[k] >= 0) {
+                WeightCtx c;
+                c.cr = cr; c.cc = cck[k]; c.R = R; c.k = P.k; c.psf = P.psf; c.psf_lds = psf_lds; c.keys = gridkeys; c.nnz = 0; c.wmax = 0.f;
+                c.jlo = jlo; c.jhi = jhi;
+                const float sum = pw_sum(c, M);
+                if (c.nnz > P.zcap || !(sum > 0.f)) rowbad = true;                      // dsm.py:194
+                sumk[k] = sum;
+                limk[k] = P.hess_thr * __fdiv_rn(c.wmax, sum);
+            }
+        }
+        if (rowbad) { bad = true; P.run_meta[cd.run_off + pos] = rp.mask << 24; continue; }
+        // pass 2: one entry per grid point inside the window of at least one pixel: the normalised weights of the four pixels and
+        // the pixels for which the entry is a LEADING one (>= hess_thr * the pixel's row maximum: the solver's approximate Hessian
+        // uses only those; S and the gradient use all).  Leading entries fill the slots from 0 upwards -- in ascending column
+        // order, so the solve kernel knows which of a pair is the row --, the others from slot nnz - 1 downwards.
+        const int64_t base = cd.ell_off + pos;
+        int hz = 0, others = 0, hzk[SDSM_RUN] = {0, 0, 0, 0}, mn[SDSM_RUN] = {0, 0, 0, 0};
+        for (int j = jlo; j < jhi; j++) {
+            const uint32_t gk = gridkeys[j];
+            const int dr = (int)(gk >> 16) - cr, gc = (int)(gk & 0xffffu);
+            if ((dr < 0 ? -dr : dr) > R) continue;
+            float nw[SDSM_RUN];
+            uint32_t lead = 0;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < SDSM_RUN; k++) {
+                const int dc = gc - cck[k];
+                nw[k] = 0.f;
+                if ((dc < 0 ? -dc : dc) <= R) {
+                    const int pidx = (R + dr) * P.k + (R + dc);
+                    nw[k] = __fdiv_rn(psf_lds ? psf_lds[pidx] : P.psf[pidx], sumk[k]);
+                    any = true;
+                    if (!(nw[k] < limk[k])) {
+                        lead |= 1u << k;
+                        // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
+                        if (hzk[k] == 0) mn[k] = j; else atomicMin(&efirst[j], mn[k]);
+                        hzk[k]++;
+                    }
+                }
+            }
+            if (!any) continue;
+            const int slot = lead ? hz++ : nnz - 1 - others++;
+            if (slot < 0 || slot >= nnz) { bad = true; break; }                       // (cannot happen: nnz was counted by the same tests)
+            const int64_t e = base + (int64_t)slot * NR;
+            f32x4 wv; wv.x = nw[0]; wv.y = nw[1]; wv.z = nw[2]; wv.w = nw[3];
+            reinterpret_cast<f32x4 *>(P.ell_w)[e] = wv;
+            P.ell_im[e] = (uint32_t)j | (lead << 16);
+        }
+        // padding (column 0, weights 0) up to the entry count of the first run of this run's 64-position chunk (a wavefront of the
+        // solve kernel walks the entries its first lane has for all of its lanes)
+        const int kh = (int)P.run_aux[cd.run_off + (pos >> 6)];
         {
-            const float zw[4] = {0.f, 0.f, 0.f, 0.f};
-            const int zi[4] = {0, 0, 0, 0};
-            for (int g = (c.nnz + 3) >> 2; g < kh; g++) store_group(g, zw, zi);
+            f32x4 zw; zw.x = 0.f; zw.y = 0.f; zw.z = 0.f; zw.w = 0.f;
+            for (int sl = nnz; sl < kh; sl++) { const int64_t e = base + (int64_t)sl * NR; reinterpret_cast<f32x4 *>(P.ell_w)[e] = zw; P.ell_im[e] = 0; }
         }
-        P.ell_meta[cd.crop_off + pos] = (uint32_t)c.nnz | ((uint32_t)hz << 16);
+        P.run_meta[cd.run_off + pos] = (uint32_t)nnz | ((uint32_t)hz << 12) | (rp.mask << 24);
         hzmax = hz > hzmax ? hz : hzmax;
     }
 }
@@ -217,7 +285,8 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __shared__ uint32_t gridkeys[T::GRID];
     __shared__ unsigned long long mom[4];
     __shared__ unsigned long long scr64[(T::WG / 64)];
-    __shared__ int scr32[(T::WG / 64)], scr32x4[4 * (T::WG / 64)];
+    __shared__ int scr32[(T::WG / 64)];
+    __shared__ unsigned scr32u[(T::WG / 64)];
     __shared__ int sh_M, sh_npos, sh_nneg, sh_err, sh_yhi;
     __shared__ int cls_cnt[SDSM_MAX_ELL_GROUPS + 1], cls_start[SDSM_MAX_ELL_GROUPS + 1], cls_run[SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int wave_cnt[(T::WG / 64)][SDSM_MAX_ELL_GROUPS + 1];
@@ -255,46 +324,56 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     }
     __syncthreads();
 
-    // ---- 1. region scan in raster order over the bounding box -> packed crop -------------------
-    const int area = cd.h * cd.w;
-    int running = 0;
+    // ---- 1. region scan in raster order over the bounding box, one aligned 4-column cell per thread and step: the region
+    //      pixels of a cell are one RUN; pixels go to the per-pixel setup arrays in scan order (low-discrepancy scatter of the
+    //      raster rank, the order the grid steps work in), runs are numbered in raster order ------------------------------------
+    const int cb0 = cd.c0 >> 2, ncw = ((cd.c0 + cd.w - 1) >> 2) - cb0 + 1;
+    const int ncell = cd.h * ncw;
+    int running = 0, nruns = 0;
     unsigned long long m_r = 0, m_c = 0, m_rr = 0, m_cc = 0;
     int npos = 0, nneg = 0, yhi = 0;                      // yhi: high word of the largest |y| (non-negative doubles order like their bits)
-    for (int base = 0; base < area; base += 4 * T::WG) {      // four chunks of 256 pixels per pair of barriers (block_excl_count4)
-        bool flag[4];
-        int rr[4], cc4[4];
-        double yv4[4];
+    for (int base = 0; base < ncell; base += T::WG) {
+        const int e = base + tid;
+        bool flag[SDSM_RUN] = {false, false, false, false};
+        double yv4[SDSM_RUN] = {0, 0, 0, 0};
+        int r = 0, ccell = 0;
+        if (e < ncell) {
+            r = e / ncw;
+            ccell = (cb0 + (e - r * ncw)) << 2;               // image column of the cell's first pixel
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = base + k * T::WG + tid;
-            flag[k] = false; rr[k] = 0; cc4[k] = 0; yv4[k] = 0;
-            if (i < area) {
-                const int r = i / cd.w, c = i - r * cd.w;
-                const size_t p = (size_t)(cd.r0 + r) * im.W + (cd.c0 + c);
-                const int a = atoms[p];                           // three independent loads (not: label -> validity -> y, a chain of round trips)
-                const uint8_t vl = valid[p];
-                const double yl = y[p];
-                flag[k] = a >= 1 && a <= T::LABELS && ((fpbits[a >> 5] >> (a & 31)) & 1u) && vl;
-                if (flag[k]) yv4[k] = yl;
-                rr[k] = r; cc4[k] = c;
+            for (int k = 0; k < SDSM_RUN; k++) {
+                const int c = ccell + k;
+                if (c >= cd.c0 && c < cd.c0 + cd.w) {
+                    const size_t p = (size_t)(cd.r0 + r) * im.W + c;
+                    const int a = atoms[p];                       // three independent loads (not: label -> validity -> y, a chain of round trips)
+                    const uint8_t vl = valid[p];
+                    const double yl = y[p];
+                    flag[k] = a >= 1 && a <= T::LABELS && ((fpbits[a >> 5] >> (a & 31)) & 1u) && vl;
+                    if (flag[k]) yv4[k] = yl;
+                }
             }
         }
-        int total, pos4[4];
-        block_excl_count4<T::WG / 64>(flag, scr32x4, pos4, &total);
+        const unsigned cnt = (unsigned)flag[0] + (unsigned)flag[1] + (unsigned)flag[2] + (unsigned)flag[3];
+        unsigned tot2;
+        const unsigned before2 = block_excl_scan_u32<T::WG / 64>(cnt | (cnt ? 1u << 16 : 0u), scr32u, &tot2);     // pixels | runs << 16 (<= 4096 pixels per step)
+        if (cnt) {
+            int q = running + (int)(before2 & 0xffffu);
+            const int rr = nruns + (int)(before2 >> 16);
+            uint32_t mask = 0;
+            const uint32_t q0 = (uint32_t)q;
+            atomicOr(&rowbits[r >> 5], 1u << (r & 31));
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (flag[k]) {
-                const int r = rr[k], c = cc4[k], pos = pos4[k];
+            for (int k = 0; k < SDSM_RUN; k++) {
+                if (!flag[k]) continue;
+                mask |= 1u << k;
+                const int c = ccell + k - cd.c0;
                 const double yv = yv4[k];
-                // scan order: low-discrepancy scatter of the raster rank (neighbouring positions are far apart in the image,
-                // which decorrelates the LDS atomics of the sparse Hessian accumulation in the solve kernel); the final
-                // crop order (step 4b) is this order, stably sorted by the size of the pixel's G~ row
-                int64_t o = cd.crop_off + (int64_t)(((unsigned long long)(running + pos) * cd.perm_inv) % (unsigned long long)cd.N);
-                if (running + pos < cd.N) {
+                if (q < cd.N) {
+                    const int64_t o = cd.crop_off + (int64_t)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N);
                     P.tmp_y[o] = yv;
                     P.tmp_rc[o] = ((uint32_t)(cd.r0 + r) << 16) | (uint32_t)(cd.c0 + c);
                 }
-                atomicOr(&rowbits[r >> 5], 1u << (r & 31));
+                q++;
                 atomicOr(&colbits[c >> 5], 1u << (c & 31));
                 const int ah = __double2hiint(yv) & 0x7fffffff;
                 yhi = ah > yhi ? ah : yhi;
@@ -304,13 +383,17 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
                     npos++; m_r += rq; m_c += cq; m_rr += rq * rq; m_cc += cq * cq;
                 }
             }
+            if (rr < cd.NRcap) P.run_q0[cd.run_off + rr] = q0 | (mask << 28);
         }
-        running += total;
+        running += (int)(tot2 & 0xffffu);
+        nruns += (int)(tot2 >> 16);
     }
     if (nneg) atomicAdd(&sh_nneg, nneg);
     if (yhi) atomicMax(&sh_yhi, yhi);
     if (npos) { atomicAdd(&sh_npos, npos); atomicAdd(&mom[0], m_r); atomicAdd(&mom[1], m_c); atomicAdd(&mom[2], m_rr); atomicAdd(&mom[3], m_cc); }
     __syncthreads();
+    const int NR = nruns;
+    const uint32_t B = scatter_mult((uint32_t)(NR > 0 ? NR : 1));         // (every thread: a few iterations of Euclid)
 
     SETUP_T(0);
     // ---- 2. compressed coordinates: delete empty rows / columns (dsm.py:185-186) ---------------
@@ -335,7 +418,8 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     s.hc = hc; s.wc = wc; s.npos = sh_npos; s.nneg = sh_nneg;
     s.sum_r = mom[0]; s.sum_c = mom[1]; s.sum_rr = mom[2]; s.sum_cc = mom[3];
     { int ex = ((sh_yhi >> 20) & 0x7ff) - 1022; s.yexp = ex < -400 ? -400 : (ex > 400 ? 400 : ex); }
-    if (running != cd.N) { s.status = ST_ERROR; if (tid == 0) *st = s; return; }          // plan / image mismatch
+    s.NR = NR;
+    if (running != cd.N || NR > cd.NRcap || NR < 1) { s.status = ST_ERROR; if (tid == 0) *st = s; return; }   // plan / image mismatch
     if (s.npos == 1 && !P.no_trivial_rule) { s.status = ST_TRIVIAL; if (tid == 0) *st = s; return; }            // objects.py:184-191 (no solve)
 
     const int S = P.subsample, R = P.R;
@@ -345,16 +429,17 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
         int r = (int)(rc >> 16) - cd.r0, c = (int)(rc & 0xffffu) - cd.c0;
         uint32_t key = ((uint32_t)rowrank[r] << 16) | (uint32_t)colrank[c];
         P.crop_cc[cd.crop_off + i] = key;
-        if (null_matrix) {                              // no G~: the final crop order is the scan order
-            P.ell_meta[cd.crop_off + i] = 0;
-            P.crop_y[cd.crop_off + i] = P.tmp_y[cd.crop_off + i];
-            P.crop_rc[cd.crop_off + i] = rc;
-        } else if (rowrank[r] % S == 0 && colrank[c] % S == 0) {                             // dsm.py:165-168
+        if (!null_matrix && rowrank[r] % S == 0 && colrank[c] % S == 0) {                   // dsm.py:165-168
             int j = atomicAdd(&sh_M, 1);
             if (j < T::GRID) gridkeys[j] = key;
         }
     }
-    if (null_matrix) { s.M = 0; s.status = ST_OK; if (tid == 0) *st = s; return; }
+    if (null_matrix) {                                  // no G~: the final order of the runs is their scan order
+        plain_runs(P, cd, NR, B, tid, T::WG);
+        s.M = 0; s.status = ST_OK;
+        if (tid == 0) *st = s;
+        return;
+    }
     __syncthreads();
     const int cap = cd.Mcap < T::GRID ? cd.Mcap : T::GRID;
     int M = sh_M;
@@ -455,11 +540,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     if (unsupported) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
     __syncthreads();
     if (6 + M > SDSM_MAX_N_SOLVE) {                      // the solve kernel only computes the elliptical model (flagged unsupported)
-        for (int i = tid; i < cd.N; i += T::WG) {
-            P.ell_meta[cd.crop_off + i] = 0;
-            P.crop_y[cd.crop_off + i] = P.tmp_y[cd.crop_off + i];
-            P.crop_rc[cd.crop_off + i] = P.tmp_rc[cd.crop_off + i];
-        }
+        plain_runs(P, cd, NR, B, tid, T::WG);
         s.M = M; s.status = ST_OK;
         if (tid == 0) *st = s;
         return;
@@ -487,28 +568,39 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __syncthreads();
 
     SETUP_T(3);
-    // ---- 4b. final crop order: stable counting sort of the scan order by the number of 4-entry groups of the pixel's
-    //      G~ row, largest first.  A wavefront of the solve kernel then reads 64 rows of (nearly) the same length and
-    //      fetches only the groups that exist (CandState.gcount), instead of every row padded to the longest one. ------
-    const int ngmax = P.zcap / 4;                        // P.zcap is a multiple of 4, <= 4 * SDSM_MAX_ELL_GROUPS
+    // ---- 4b. final order of the runs: stable counting sort of their scan order by the number of G~ entries of the run (grid
+    //      points inside the window of at least one of its pixels), largest first.  A wavefront of the solve kernel then walks 64
+    //      runs of (nearly) the same length: as many entries as its first lane has. ------
+    const int zshift = P.zshift;
+    const int ngmax = (P.zcap_run + (1 << zshift) - 1) >> zshift;   // <= SDSM_MAX_ELL_GROUPS
     for (int k = tid; k <= ngmax; k += T::WG) { cls_cnt[k] = 0; cls_run[k] = 0; }
     __syncthreads();
     int cntmax = 0;
-    for (int q = tid; q < cd.N; q += T::WG) {           // raster order (coherent wavefronts), see rows_of_ranks
-        const int i = (int)(((unsigned long long)q * cd.perm_inv) % (unsigned long long)cd.N);
-        uint32_t key = P.crop_cc[cd.crop_off + i];
-        const int cr = key >> 16, cc = key & 0xffffu;
+    for (int rr = tid; rr < NR; rr += T::WG) {          // raster order (coherent wavefronts), see rows_of_runs
+        const int si = (int)(((unsigned long long)rr * B) % (unsigned long long)NR);
+        const RunPixels rp = run_pixels(P, cd, rr);
+        int cr = 0, cck[SDSM_RUN];
+#pragma unroll
+        for (int k = 0; k < SDSM_RUN; k++) {
+            cck[k] = -(1 << 20);
+            if (rp.idx[k] >= 0) { const uint32_t key = P.crop_cc[cd.crop_off + rp.idx[k]]; cr = key >> 16; cck[k] = key & 0xffffu; }
+        }
         int cnt = 0;
         const int jlo = growstart[cr - R > 0 ? cr - R : 0], jhi = cr + R + 1 < hc ? growstart[cr + R + 1] : M;
         for (int j = jlo; j < jhi; j++) {
-            int dr = (int)(gridkeys[j] >> 16) - cr, dc = (int)(gridkeys[j] & 0xffffu) - cc;
-            dr = dr < 0 ? -dr : dr; dc = dc < 0 ? -dc : dc;
-            cnt += (dr <= R && dc <= R) ? 1 : 0;
+            int dr = (int)(gridkeys[j] >> 16) - cr;
+            const int gc = (int)(gridkeys[j] & 0xffffu);
+            dr = dr < 0 ? -dr : dr;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < SDSM_RUN; k++) { int dc = gc - cck[k]; dc = dc < 0 ? -dc : dc; any = any || dc <= R; }
+            cnt += (dr <= R && any) ? 1 : 0;
         }
         cntmax = cnt > cntmax ? cnt : cntmax;
-        int k = (cnt + 3) >> 2;
-        k = k > ngmax ? ngmax : k;                       // rows longer than zcap are reported as errors in step 5
-        P.dist[cd.crop_off + i] = (uint32_t)k;
+        int k = (cnt + (1 << zshift) - 1) >> zshift;
+        k = k > ngmax ? ngmax : k;                       // runs with more entries than zcap_run are reported as errors in step 5
+        P.dist[cd.crop_off + si] = (uint32_t)cnt;
+        P.inv[cd.crop_off + si] = (uint32_t)k;
         atomicAdd(&cls_cnt[k], 1);
     }
     __syncthreads();
@@ -519,11 +611,11 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __syncthreads();
     {
         const int lane = tid & 63, wave = tid >> 6;
-        for (int base = 0; base < cd.N; base += T::WG) {
+        for (int base = 0; base < NR; base += T::WG) {
             for (int e = tid; e < (T::WG / 64) * (ngmax + 1); e += T::WG) wave_cnt[e / (ngmax + 1)][e % (ngmax + 1)] = 0;
             __syncthreads();
             const int i = base + tid;
-            const int k = i < cd.N ? (int)P.dist[cd.crop_off + i] : -1;
+            const int k = i < NR ? (int)P.inv[cd.crop_off + i] : -1;
             int within = 0;
             unsigned long long todo = __ballot(k >= 0);
             while (todo) {                               // one pass per distinct class present in the wavefront
@@ -540,7 +632,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
             if (k >= 0) {
                 int before = 0;
                 for (int w2 = 0; w2 < wave; w2++) before += wave_cnt[w2][k];
-                P.dist[cd.crop_off + i] = (uint32_t)(cls_start[k] + cls_run[k] + before + within);
+                P.inv[cd.crop_off + i] = (uint32_t)(cls_start[k] + cls_run[k] + before + within);
             }
             __syncthreads();
             for (int k2 = tid; k2 <= ngmax; k2 += T::WG) {
@@ -556,20 +648,16 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __syncthreads();
 
     SETUP_T(4);
-    // group count of the first position of every 64-position chunk (padding target of its rows), for rows_of_ranks
-    for (int t = tid; t * 64 < cd.N; t += T::WG) {
+    // entry count the rows of every 64-position chunk are padded to: that of the chunk's first run, rounded up to its sort class
+    // (runs of a class are not sorted among themselves), for rows_of_runs
+    for (int t = tid; t * 64 < NR; t += T::WG) {
         int kh = 0;
         const int head = t * 64;
         for (int k2 = ngmax; k2 >= 0; k2--) if (cls_cnt[k2] > 0 && head >= cls_start[k2]) kh = k2;
-        P.inv[cd.crop_off + t] = (uint32_t)kh;
+        P.run_aux[cd.run_off + t] = (uint32_t)(kh << zshift);
     }
     const int zmax = -block_min_i32<T::WG / 64>(-cntmax, scr32);
     s.M = M; s.zmax = zmax; s.hzmax = 0;
-    for (int j = 0; j < 8; j++) {                        // positions [0, gcount[j]) have rows of more than 4 j entries
-        int acc = 0;
-        for (int k2 = j + 1; k2 <= ngmax; k2++) acc += cls_cnt[k2];
-        s.gcount[j] = acc;
-    }
     __syncthreads();
     if (cd.wide_g > 0) {
         // a very large region: its rows are built by the members of its workgroup group (sdsm_k_setup_rows), which also
@@ -594,7 +682,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     }
     bool bad = false;
     int hzmax = 0;
-    rows_of_ranks(P, cd, M, R, hc, gridkeys, growstart, psf_lds, efirst, tid, cd.N, T::WG, bad, hzmax);
+    rows_of_runs(P, cd, NR, B, M, R, hc, gridkeys, growstart, psf_lds, efirst, tid, NR, T::WG, bad, hzmax);
     if (bad) atomicOr(&sh_err, 1);
     hzmax = -block_min_i32<T::WG / 64>(-hzmax, scr32);
     __syncthreads();
@@ -628,7 +716,8 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
     const CandDesc cd = P.cand[ci];
     CandState *st = &P.state[ci];
     if (st->status != ST_OK || st->env_size != -1) return;       // nothing pending (trivial, no G~, unsupported, ...)
-    const int M = st->M, hc = st->hc, R = P.R, G = cd.wide_g;
+    const int M = st->M, hc = st->hc, R = P.R, G = cd.wide_g, NR = st->NR;
+    const uint32_t B = scatter_mult((uint32_t)(NR > 0 ? NR : 1));
     int *sync = reinterpret_cast<int *>(P.wide_pool + cd.wide_off);   // [2] ticket, [3] error flag (zeroed by sdsm_k_setup)
     for (int j = tid; j < M; j += SDSM_WG) { gridkeys[j] = P.grid_rc[cd.xi_off + j]; efirst[j] = j; }
     const float *psf_lds = nullptr;
@@ -643,11 +732,11 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
         growstart[r] = (uint16_t)lo;
     }
     __syncthreads();
-    const int chunk = (cd.N + G - 1) / G;
-    const int q0 = g * chunk < cd.N ? g * chunk : cd.N, q1 = q0 + chunk < cd.N ? q0 + chunk : cd.N;
+    const int chunk = (NR + G - 1) / G;
+    const int q0 = g * chunk < NR ? g * chunk : NR, q1 = q0 + chunk < NR ? q0 + chunk : NR;
     bool bad = false;
     int hzmax = 0;
-    rows_of_ranks(P, cd, M, R, hc, gridkeys, growstart, psf_lds, efirst, q0 + tid, q1, SDSM_WG, bad, hzmax);
+    rows_of_runs(P, cd, NR, B, M, R, hc, gridkeys, growstart, psf_lds, efirst, q0 + tid, q1, SDSM_WG, bad, hzmax);
     hzmax = -block_min_i32(-hzmax, scr32);
     __syncthreads();
     for (int j = tid; j < M; j += SDSM_WG) if (efirst[j] < j) atomicMin(&P.env_fst[cd.xi_off + j], efirst[j]);

@@ -13,14 +13,19 @@
 // invariant under affine re-parametrisation of theta).
 //
 // One full evaluation (psi, gradient, Hessian) of a candidate with n = 6 + M parameters:
-//   every lane owns pixels: coalesced read of the packed crop (y f64 + (row,col) u16x2 = 12 B / pixel) and of the
-//   pixel's row of G~ (4 entries per load, only the groups its 64-position chunk has, all loads issued before the first
-//   use), S, the logistic loss without libm, residual r and curvature weight d.  psi, the 6 polynomial gradient entries
-//   and the 6x6 polynomial Hessian block are per-lane register sums reduced with a reduce-scatter butterfly + one LDS
-//   hop.  The xi part of the gradient (every entry of the row) and of the Hessian (the row's leading entries, weight
-//   >= 10 % of the row maximum: the solver's approximate Hessian, stored as an envelope) is added straight into LDS with
-//   ds_add_f64; the crop order scatters neighbouring pixels so that the 64 lanes of a wave touch different entries.
-//   One line-search sweep evaluates psi(x + t d) for 8 step lengths in a single pass (S is linear in t).
+//   every lane owns RUNS -- the (up to four) region pixels of one image row inside one aligned 4-column cell, which share the row
+//   coordinate u and ONE list of G~ entries (a grid point with the float32 weights of the four pixels; 0 where the point is
+//   outside a pixel's window): coalesced reads of the packed crop (4 y f64 + (row, col) + meta = 10 B / pixel) and of the run's
+//   entries (16 B weights + 4 B column index per entry and lane), S of the four pixels, the logistic loss without libm, residuals r
+//   and curvature weights d.  Everything that is summed over the pixels is summed in FIXED POINT: a contribution becomes an
+//   integer multiple of 2^e (one fma against 1.5 * 2^(52 + e)) and is added with an integer atomic -- the polynomial (theta) parts
+//   of gradient and Hessian as 21 coordinate moments in per-lane LDS slots, the xi part of the gradient (every entry of the run)
+//   and of the Hessian (the run's leading entries, weight >= 10 % of the row maximum: the solver's approximate Hessian, stored as
+//   an envelope) straight into their LDS entries, ONE atomic per entry and run (the four pixels' products are added first).
+//   Integer sums do not depend on the order of the additions; psi -- whose terms have no a-priori bound -- is summed per chunk of
+//   64 runs by a wavefront butterfly and the chunk totals are added in a fixed order.  A candidate's numbers therefore do not
+//   depend on the workgroup size, the size class, the number of workgroups that share it or anything else in its launch.
+//   One line-search sweep evaluates psi(x + t d) for 4 step lengths in a single pass (S is linear in t).
 #include "sdsm_common.h"
 #include <climits>
 
@@ -44,7 +49,9 @@ namespace {
 #define FINE_ADD(slot) do { } while (0)
 #define FINE_START() do { } while (0)
 #endif
-#define ZREG (4 * SDSM_ELL_GROUPS_REG)   // ELL slots held in registers by the sparse path (covers zcap = 25 of the default ratios)
+#ifndef EBATCH
+#define EBATCH 4          // entries of a run requested together (16-byte weights + 4-byte index per lane and entry)
+#endif
 #ifndef SDSM_FACTOR_DIV
 #define SDSM_FACTOR_DIV 1
 #ifndef SDSM_K1_THREADS
@@ -55,7 +62,8 @@ namespace {
 #define SDSM_K1B_WPE 2
 #endif
 #endif
-#define HZREG 12         // leading ('significant') slots unrolled for the approximate Hessian
+#define HZREG SDSM_HZREG   // leading ('significant') entries of a run unrolled for the approximate Hessian
+#define NSLOT SDSM_MSLOTS
 
 // Compile-time LDS layout (offsets in doubles from the start of dynamic LDS).
 // The Hessian lives in ENVELOPE storage (BatchParams.env_fst / env_rb): unknowns ordered xi_0 .. xi_{M-1}, theta_0 ..
@@ -69,7 +77,7 @@ struct Lay {
     static constexpr bool GLOBAL_H = GLOBALH;      // Hessian in global memory (envelope larger than LDS)
     static constexpr int W = NMAX + 2;             // vectors are indexed up to n (right-hand-side row) inclusive
     static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
-    static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, IB = FLAG + 2;
+    static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, MS = FLAG + 2, IB = MS + 21 * NSLOT;   // MS: fixed-point moment accumulators, 21 sums x NSLOT lane slots
     static constexpr int NPANEL = NMAX / SDSM_PANEL + 2;
     static constexpr int IB_DOUBLES = (2 * W + NPANEL + 1) / 2;      // int arrays: rb[W], fst[W], rend[NPANEL]
     static constexpr int HP = IB + IB_DOUBLES;
@@ -87,23 +95,26 @@ struct Lay {
 #define PROF_PARAM
 #endif
 
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef const f64x2 SDSM_GLOBAL *g_cf64x2_p;
+
 struct Cand {                       // per-candidate global pointers (already offset) and scalars
-    g_cdouble_p crop_y;
-    g_cu32_p crop_rc;
-    g_cf32x4_p ell_w4;                  // group j of position p: element j * N + p (4 weights)
-    g_cu16x4_p ell_i4;                  // (4 column indices)
-    g_cu32_p ell_meta;                  // row entries | Hessian entries << 16
-    int gcount[SDSM_ELL_GROUPS_REG];    // positions [0, gcount[j]) have rows of more than 4 j entries
+    g_cf64x2_p crop_y2;                 // run p: elements 2 p, 2 p + 1 (four intensities)
+    g_cu32_p crop_rc;                   // (row << 16) | first column of the cell
+    g_cu32_p meta;                      // entries | leading entries << 12 | present pixels << 24
+    g_cu32_p aux;                       // [chunk of 64 positions]: entries the rows of the chunk are padded to
+    g_cf32x4_p ell_w4;                  // entry j of run position p: element j * NR + p (the four pixels' weights)
+    g_cu32_p ell_im;                    // (column | leading-for-pixel bits << 16)
     double *hglob;                      // flat pointer: Hessian of the global-memory class
-    int N, zmax, hzmax, env_size;
-    int p_lo, p_hi;                     // the crop positions this workgroup covers in a pass (the whole crop unless it is one of a group)
+    int N, NR, hzmax, env_size;         // region pixels, runs
+    int p_lo, p_hi;                     // the run positions this workgroup covers in a pass (all of them unless it is one of a group)
     int wg, wG;                         // member index and size of the workgroup group (wG = 1: none)
     double *wpool;                      // the group's block of BatchParams.wide_pool
     long long wtimeout;                 // BatchParams.wide_timeout
     double rmid, cmid, inv_hr, inv_hc;   // local coordinates u = (r - rmid) * inv_hr
     double scale, epsilon, alpha;
     double reg0;                        // alpha * sqrt(epsilon) * M: the regulariser's value at xi = 0 (dsm.py:325-326)
-    int fxh_hi, fxg_hi;                 // fixed-point sums of the sparse pass (fx_add): high words of the constants 1.5 * 2^(52 + e), Hessian / gradient
+    int yexp;                           // |y| < 2^yexp over the region (setup kernel): scale of the fixed-point sums (fx_exponents)
 };
 
 // The evaluators are real (non-inlined) functions and receive the candidate by reference: its fields then come out of a
@@ -129,7 +140,8 @@ __device__ __forceinline__ CandDesc uniform_desc(const CandDesc &d)
     u.crop_off = uni((long long)d.crop_off); u.ell_off = uni((long long)d.ell_off); u.mask_off = uni((long long)d.mask_off); u.xi_off = uni((long long)d.xi_off);
     u.N = uni(d.N); u.r0 = uni(d.r0); u.c0 = uni(d.c0); u.h = uni(d.h); u.w = uni(d.w); u.fp_off = uni(d.fp_off); u.fp_len = uni(d.fp_len);
     u.Mcap = uni(d.Mcap); u.perm_inv = uni(d.perm_inv); u.wide_g = uni(d.wide_g);
-    u.hglob_off = uni((long long)d.hglob_off); u.wide_off = uni((long long)d.wide_off); u.image = uni(d.image); u.pad0 = 0;
+    u.hglob_off = uni((long long)d.hglob_off); u.wide_off = uni((long long)d.wide_off); u.image = uni(d.image); u.NRcap = uni(d.NRcap);
+    u.run_off = uni((long long)d.run_off); u.pad1 = 0;
     return u;
 }
 __device__ __forceinline__ CandState uniform_state(const CandState &d)
@@ -137,23 +149,19 @@ __device__ __forceinline__ CandState uniform_state(const CandState &d)
     CandState u;
     u.M = uni(d.M); u.status = uni(d.status); u.hc = uni(d.hc); u.wc = uni(d.wc); u.npos = uni(d.npos); u.zmax = uni(d.zmax);
     u.sum_r = uni(d.sum_r); u.sum_c = uni(d.sum_c); u.sum_rr = uni(d.sum_rr); u.sum_cc = uni(d.sum_cc);
-    u.hzmax = uni(d.hzmax); u.env_size = uni(d.env_size); u.nneg = uni(d.nneg); u.yexp = uni(d.yexp);
-#pragma unroll
-    for (int j = 0; j < 8; j++) u.gcount[j] = uni(d.gcount[j]);
+    u.hzmax = uni(d.hzmax); u.env_size = uni(d.env_size); u.nneg = uni(d.nneg); u.yexp = uni(d.yexp); u.NR = uni(d.NR);
     return u;
 }
 __device__ __forceinline__ Cand uniform_cand(const Cand &c)
 {
     Cand u;
-    u.crop_y = uni(c.crop_y); u.crop_rc = uni(c.crop_rc); u.ell_w4 = uni(c.ell_w4); u.ell_i4 = uni(c.ell_i4); u.ell_meta = uni(c.ell_meta);
-#pragma unroll
-    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) u.gcount[j] = uni(c.gcount[j]);
+    u.crop_y2 = uni(c.crop_y2); u.crop_rc = uni(c.crop_rc); u.meta = uni(c.meta); u.aux = uni(c.aux); u.ell_w4 = uni(c.ell_w4); u.ell_im = uni(c.ell_im);
     u.hglob = (double *)uni((unsigned long long)c.hglob);
-    u.N = uni(c.N); u.zmax = uni(c.zmax); u.hzmax = uni(c.hzmax); u.env_size = uni(c.env_size);
+    u.N = uni(c.N); u.NR = uni(c.NR); u.hzmax = uni(c.hzmax); u.env_size = uni(c.env_size);
     u.p_lo = uni(c.p_lo); u.p_hi = uni(c.p_hi); u.wg = uni(c.wg); u.wG = uni(c.wG); u.wpool = (double *)uni((unsigned long long)c.wpool); u.wtimeout = uni(c.wtimeout);
     u.rmid = uni(c.rmid); u.cmid = uni(c.cmid); u.inv_hr = uni(c.inv_hr); u.inv_hc = uni(c.inv_hc);
     u.scale = uni(c.scale); u.epsilon = uni(c.epsilon); u.alpha = uni(c.alpha); u.reg0 = uni(c.reg0);
-    u.fxh_hi = uni(c.fxh_hi); u.fxg_hi = uni(c.fxg_hi);
+    u.yexp = uni(c.yexp);
     return u;
 }
 
@@ -166,6 +174,16 @@ __device__ __forceinline__ int opaque_tid() { int t = threadIdx.x; asm volatile(
 __device__ __forceinline__ double fresh(double v) { asm volatile("" : "+s"(v)); return v; }
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
+
+// Sum of f(0) .. f(cnt - 1), computed by EVERY wavefront for itself: lane l adds f(l), f(l + 64), ... in that order, then the xor
+// butterfly (whose result is the same in all lanes).  The same bits in every wavefront and for every workgroup size; no barrier.
+template <class F>
+__device__ __forceinline__ double wave_canon_sum(int cnt, F &&f)
+{
+    double s = 0;
+    for (int j = (int)(threadIdx.x & 63); j < cnt; j += 64) s += f(j);
+    return wave_sum(s);
+}
 
 template <class L> __device__ __forceinline__ double *hess_ptr(const Cand &c) { if constexpr (L::GLOBAL_H) return c.hglob; else return SD + L::HP; }
 #define RBP ((int *)(SD + L::IB))              // rb[i]: entry (i, j) of the Hessian / factor is at rb[i] + j (logical order)
@@ -211,50 +229,73 @@ __device__ __forceinline__ bool wide_barrier(const Cand &c, int phase0)
     return __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
-// All-reduce of up to three LDS (or global) arrays of doubles, in place.  Returns false if the group was given up.
-// Long vectors (the Hessian envelope: ~10 k doubles) as reduce-scatter + all-gather: member g adds the wG partials of ITS share of the
-// entries (in member order, as every member did for all entries before: the same sums bit for bit) and leaves the totals in its own
-// publication block, a second group barrier, then everybody reads the totals -- 2 instead of wG reads per entry and member, for one more
-// barrier.  Short vectors (line-search values, the 28 sums of the elliptical model) keep the single barrier.
-// Publication slots alternate per OPERATION (WIDE_OPS): a member can be at most one operation ahead of the slowest one.
+// One exchange of a workgroup group.  Publication slots alternate per OPERATION (WIDE_OPS): a member can be at most one operation
+// ahead of the slowest one.  A member's block of a slot: [0, WIDE_F0) integer payload, [WIDE_F0] number of psi-type sums that follow.
 #define WIDE_OPS (reinterpret_cast<int *>(SD + L::FLAG) + 3)
 #define WIDE_RS_MIN 512
+#define WIDE_F0 (SDSM_WIDE_PBUF - SDSM_WIDE_FCAP)
 template <class L>
-__device__ __forceinline__ bool wide_allreduce(const Cand &c, double *a0, int n0, double *a1 = nullptr, int n1 = 0, double *a2 = nullptr, int n2 = 0)
+__device__ __forceinline__ double *wide_mine(const Cand &c)
 {
-    if (c.wG <= 1) return true;
+    return c.wpool + SDSM_WIDE_SYNC + (size_t)(*WIDE_OPS & 1) * c.wG * SDSM_WIDE_PBUF + (size_t)c.wg * SDSM_WIDE_PBUF;
+}
+
+// Completes the exchange: (i) up to three arrays of FIXED-POINT sums (raw 64-bit integers, in LDS or global memory) are all-reduced in
+// place by integer addition -- order-free, so the totals do not depend on the number of members; long vectors (the Hessian envelope:
+// ~10 k entries) as reduce-scatter + all-gather: member g adds the wG partials of ITS share of the entries and leaves the totals in its
+// own publication block, a second group barrier, then everybody reads the totals -- 2 instead of wG reads per entry and member.
+// (ii) psi-type sums: every member has published nf (at [WIDE_F0]) super-chunk sums of K values each; tot[k] = all of them, added one
+// by one in position order (members cover consecutive slices): exactly the additions a single workgroup makes (run_pass).
+// Returns false if the group was given up.
+template <class L, int K>
+__device__ __forceinline__ bool wide_finish(const Cand &c, double (&tot)[K], double *a0 = nullptr, int n0 = 0, double *a1 = nullptr, int n1 = 0, double *a2 = nullptr, int n2 = 0)
+{
+    typedef unsigned long long u64;
     const int phase = *WIDE_PHASE, ops = *WIDE_OPS;
-    double *slot = c.wpool + SDSM_WIDE_SYNC + (size_t)(ops & 1) * c.wG * SDSM_WIDE_PBUF;
-    double *mine = slot + (size_t)c.wg * SDSM_WIDE_PBUF;
+    double *slotd = c.wpool + SDSM_WIDE_SYNC + (size_t)(ops & 1) * c.wG * SDSM_WIDE_PBUF;
+    u64 *slot = reinterpret_cast<u64 *>(slotd);
+    u64 *mine = slot + (size_t)c.wg * SDSM_WIDE_PBUF;
+    u64 *b0 = reinterpret_cast<u64 *>(a0), *b1 = reinterpret_cast<u64 *>(a1), *b2 = reinterpret_cast<u64 *>(a2);
     const int tid = threadIdx.x;
-    for (int e = tid; e < n0; e += L::WGS) mine[e] = a0[e];
-    for (int e = tid; e < n1; e += L::WGS) mine[n0 + e] = a1[e];
-    for (int e = tid; e < n2; e += L::WGS) mine[n0 + n1 + e] = a2[e];
+    for (int e = tid; e < n0; e += L::WGS) mine[e] = b0[e];
+    for (int e = tid; e < n1; e += L::WGS) mine[n0 + e] = b1[e];
+    for (int e = tid; e < n2; e += L::WGS) mine[n0 + n1 + e] = b2[e];
     bool ok = wide_barrier<L>(c, phase);
     if (tid == 0) *WIDE_OPS = ops + 1;                           // (everybody read it before the barrier above)
     const int nt = n0 + n1 + n2;
     if (nt < WIDE_RS_MIN) {
         for (int e = tid; e < nt; e += L::WGS) {
-            double v = 0;
+            u64 v = 0;
             for (int m = 0; m < c.wG; m++) v += slot[(size_t)m * SDSM_WIDE_PBUF + e];
-            if (!ok) v = NAN;                                    // group given up: every member sees non-finite values and fails the solve
-            if (e < n0) a0[e] = v; else if (e < n0 + n1) a1[e - n0] = v; else a2[e - n0 - n1] = v;
+            if (e < n0) b0[e] = v; else if (e < n0 + n1) b1[e - n0] = v; else b2[e - n0 - n1] = v;
         }
     } else {
         const int chunk = (((nt + c.wG - 1) / c.wG) + 7) & ~7;
         const int lo = c.wg * chunk, hi = lo + chunk < nt ? lo + chunk : nt;
         for (int e = lo + tid; e < hi; e += L::WGS) {
-            double v = 0;
+            u64 v = 0;
             for (int m = 0; m < c.wG; m++) v += slot[(size_t)m * SDSM_WIDE_PBUF + e];
             mine[e] = v;
         }
         ok = wide_barrier<L>(c, phase + 1) && ok;
         for (int e = tid; e < nt; e += L::WGS) {
-            double v = slot[(size_t)(e / chunk) * SDSM_WIDE_PBUF + e];
-            if (!ok) v = NAN;
-            if (e < n0) a0[e] = v; else if (e < n0 + n1) a1[e - n0] = v; else a2[e - n0 - n1] = v;
+            const u64 v = slot[(size_t)(e / chunk) * SDSM_WIDE_PBUF + e];
+            if (e < n0) b0[e] = v; else if (e < n0 + n1) b1[e - n0] = v; else b2[e - n0 - n1] = v;
         }
     }
+    double run[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) run[k] = 0;
+    for (int m = 0; m < c.wG; m++) {
+        const double *f = slotd + (size_t)m * SDSM_WIDE_PBUF + WIDE_F0;
+        const int nf = (int)f[0];
+        for (int j = 0; j < nf; j++) {
+#pragma unroll
+            for (int k = 0; k < K; k++) run[k] += f[1 + j * K + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) tot[k] = ok ? run[k] : NAN;     // group given up: every member sees a non-finite value and fails the solve
     __syncthreads();
     return ok;
 }
@@ -350,105 +391,176 @@ __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, dou
     *dcurv = yv * yv * (bad ? t : kap);
 }
 
-// Row of G~ for crop position p into registers.  Positions are sorted by row length (4-entry groups, longest first) and
-// rows are zero-padded to the group count of the first position of their 64-position chunk, so group j is fetched by a
-// wavefront iff its first position needs it: a uniform test against CandState.gcount, one 16-byte + one 8-byte load per
-// lane and group, all issued before the first use.
-// Column indices of a row stay packed two per register (as loaded); RID(ip, s) with a compile-time s is a shift or a mask.
-typedef unsigned RowIds[ZREG / 2];
-#define RID(ip, s) (((s) & 1) ? (int)((ip)[(s) >> 1] >> 16) : (int)((ip)[(s) >> 1] & 0xffffu))
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef const u32x2 SDSM_GLOBAL *g_cu32x2_p;
-
-__device__ __forceinline__ void load_row(const Cand &c, int p, float (&w)[ZREG], RowIds &ip)
+// ---------------------------------------------------------------------------------------------------------
+// A pass over the runs.  `body(p, active, v)` handles run position p (active == false: a lane beyond the slice, v must come out 0)
+// and returns the run's K psi-type values; everything else a pass sums goes through fixed-point atomics inside the body.
+// The K values are summed per CHUNK of 64 positions by a wavefront butterfly (a chunk is the same set of runs whatever the
+// workgroup size), the chunk totals in a fixed order: sequentially inside a super-chunk of SDSM_SUPER chunks, then the super-chunk
+// sums sequentially -- tot does not depend on the workgroup size nor (wide_finish) on the number of workgroups sharing the
+// candidate, whose slices are whole super-chunks.  Chunk totals live in L::TMP (free outside factor_solve); slices with more
+// chunks than fit there are walked in segments.  wG > 1: the super-chunk sums are PUBLISHED, the caller completes the exchange
+// (wide_finish); tot is then undefined here.
+// ---------------------------------------------------------------------------------------------------------
+template <class L, int K, class Body>
+__device__ __forceinline__ void run_pass(const Cand &c, double (&tot)[K], Body &&body)
 {
-    const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
+    constexpr int SEGC = ((L::W / K) / SDSM_SUPER) * SDSM_SUPER;     // chunks per segment
+    static_assert(SEGC >= SDSM_SUPER, "chunk totals do not fit");
+    double *ct = SD + L::TMP;
+    const int tid = opaque_tid(), lane = tid & 63;
+    double acc[K];
 #pragma unroll
-    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
-        if (q0 < c.gcount[j]) {
-            const f32x4 wv = c.ell_w4[(size_t)j * c.N + p];
-            const u32x2 iv = ((g_cu32x2_p)c.ell_i4)[(size_t)j * c.N + p];
-            w[4 * j] = wv.x; w[4 * j + 1] = wv.y; w[4 * j + 2] = wv.z; w[4 * j + 3] = wv.w;
-            ip[2 * j] = iv.x; ip[2 * j + 1] = iv.y;
+    for (int k = 0; k < K; k++) acc[k] = 0;
+    double *pub = c.wG > 1 ? wide_mine<L>(c) + WIDE_F0 : nullptr;
+    int npub = 0;
+    for (int seg0 = c.p_lo; seg0 < c.p_hi; seg0 += SEGC * 64) {
+        const int seg1 = seg0 + SEGC * 64 < c.p_hi ? seg0 + SEGC * 64 : c.p_hi;
+        __builtin_amdgcn_s_setprio(0);
+        for (int pb = seg0 + (tid & ~63); pb < seg1; pb += L::WGS) {
+            const int p = pb + lane;
+            double v[K];
+            body(p, p < seg1, v);
+#pragma unroll
+            for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < K; k++) ct[((pb - seg0) >> 6) * K + k] = v[k];
+            }
+        }
+        __builtin_amdgcn_s_setprio(2);
+        __syncthreads();
+        const int nch = (seg1 - seg0 + 63) >> 6;
+        if (c.wG <= 1) {
+            for (int sc = 0; sc < nch; sc += SDSM_SUPER) {           // (every thread: the same LDS words in the same order)
+                double part[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) part[k] = 0;
+                const int e1 = sc + SDSM_SUPER < nch ? sc + SDSM_SUPER : nch;
+                for (int i = sc; i < e1; i++) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) part[k] += ct[i * K + k];
+                }
+#pragma unroll
+                for (int k = 0; k < K; k++) acc[k] += part[k];
+            }
         } else {
+            const int nsc = (nch + SDSM_SUPER - 1) / SDSM_SUPER;
+            for (int t = tid; t < nsc * K; t += L::WGS) {
+                const int sc = (t / K) * SDSM_SUPER, k = t % K;
+                const int e1 = sc + SDSM_SUPER < nch ? sc + SDSM_SUPER : nch;
+                double part = 0;
+                for (int i = sc; i < e1; i++) part += ct[i * K + k];
+                if (npub + t < SDSM_WIDE_FCAP - 8) pub[1 + npub + t] = part;
+            }
+            npub += nsc * K;
+        }
+        __syncthreads();                                             // ct is rewritten by the next segment / the next pass
+    }
+    if (c.wG > 1) { if (tid == 0) pub[0] = (double)(npub / K); }
 #pragma unroll
-            for (int k = 0; k < 4; k++) w[4 * j + k] = 0.f;
-            ip[2 * j] = 0; ip[2 * j + 1] = 0;
+    for (int k = 0; k < K; k++) tot[k] = uni(acc[k]);
+}
+
+// The pixels of a run: local coordinates (one row: u; consecutive columns: v[k]), intensities (0 for the absent ones), presence bits.
+struct RunPix { double u, v[SDSM_RUN], y[SDSM_RUN]; unsigned pm; int nnz, hz; };
+__device__ __forceinline__ void load_run(const Cand &c, int p, bool active, RunPix &rp)
+{
+    uint32_t meta = 0, rc = 0;
+    f64x2 ya = {0, 0}, yb = {0, 0};
+    if (active) { meta = c.meta[p]; rc = c.crop_rc[p]; ya = c.crop_y2[2 * (size_t)p]; yb = c.crop_y2[2 * (size_t)p + 1]; }
+    rp.y[0] = ya.x; rp.y[1] = ya.y; rp.y[2] = yb.x; rp.y[3] = yb.y;
+    rp.pm = meta >> 24; rp.nnz = (int)(meta & 0xfffu); rp.hz = (int)((meta >> 12) & 0xfffu);
+    rp.u = ((double)(rc >> 16) - c.rmid) * c.inv_hr;
+    const int col0 = (int)(rc & 0xffffu);
+#pragma unroll
+    for (int k = 0; k < SDSM_RUN; k++) rp.v[k] = ((double)(col0 + k) - c.cmid) * c.inv_hc;
+}
+__device__ __forceinline__ void poly_surface(const RunPix &rp, const double *xv, double (&S)[SDSM_RUN])
+{
+    const double a = (rp.u * rp.u) * xv[0] + (2 * rp.u) * xv[3] + xv[5], b2 = 2 * rp.u * xv[2] + 2 * xv[4];
+#pragma unroll
+    for (int k = 0; k < SDSM_RUN; k++) S[k] = (rp.v[k] * rp.v[k]) * xv[1] + rp.v[k] * b2 + a;
+}
+
+// entries the rows of the chunk of position p are padded to (uniform: one scalar load per wavefront and chunk)
+__device__ __forceinline__ int chunk_entries(const Cand &c, int pb) { return (int)c.aux[pb >> 6]; }
+
+// S += G~ xi for the four pixels of run p: the entries are requested EBATCH at a time (all loads of a batch before the first use)
+template <int STRIDE>
+__device__ __forceinline__ void smooth_add(const Cand &c, const double *xv, int p, bool active, int kh, double (&S)[SDSM_RUN])
+{
+    for (int j0 = 0; j0 < kh; j0 += EBATCH) {
+        f32x4 w[EBATCH];
+        uint32_t im[EBATCH];
+#pragma unroll
+        for (int t = 0; t < EBATCH; t++) {
+            w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
+            if (j0 + t < kh && active) { w[t] = c.ell_w4[(size_t)(j0 + t) * c.NR + p]; im[t] = c.ell_im[(size_t)(j0 + t) * c.NR + p]; }
+        }
+#pragma unroll
+        for (int t = 0; t < EBATCH; t++) {
+            if (j0 + t < kh) {
+                const double xi = xv[STRIDE * (6 + (int)(im[t] & 0xffffu))];
+                S[0] += (double)w[t].x * xi; S[1] += (double)w[t].y * xi; S[2] += (double)w[t].z * xi; S[3] += (double)w[t].w * xi;
+            }
         }
     }
 }
 
-__device__ __forceinline__ double gather_row(const Cand &c, const double *xv, int p, const float (&w)[ZREG], const RowIds &ip)
+// The same for S(x) and S(d) at once: xd holds the pairs (x_j, d_j), one 16-byte LDS read per entry
+__device__ __forceinline__ void smooth_add2(const Cand &c, const double *xd, int p, bool active, int kh, double (&S0)[SDSM_RUN], double (&Sd)[SDSM_RUN])
 {
-    const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
-    double gx = 0;
+    for (int j0 = 0; j0 < kh; j0 += EBATCH) {
+        f32x4 w[EBATCH];
+        uint32_t im[EBATCH];
 #pragma unroll
-    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
-        if (q0 < c.gcount[j]) {
+        for (int t = 0; t < EBATCH; t++) {
+            w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
+            if (j0 + t < kh && active) { w[t] = c.ell_w4[(size_t)(j0 + t) * c.NR + p]; im[t] = c.ell_im[(size_t)(j0 + t) * c.NR + p]; }
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) gx += (double)w[4 * j + k] * xv[6 + RID(ip, 4 * j + k)];
+        for (int t = 0; t < EBATCH; t++) {
+            if (j0 + t < kh) {
+                const double *pr = xd + 2 * (6 + (int)(im[t] & 0xffffu));
+                const double xi = pr[0], di = pr[1];
+                const double w0 = (double)w[t].x, w1 = (double)w[t].y, w2 = (double)w[t].z, w3 = (double)w[t].w;
+                S0[0] += w0 * xi; S0[1] += w1 * xi; S0[2] += w2 * xi; S0[3] += w3 * xi;
+                Sd[0] += w0 * di; Sd[1] += w1 * di; Sd[2] += w2 * di; Sd[3] += w3 * di;
+            }
         }
     }
-    return gx;
 }
 
-// scalar accessors (rows longer than ZREG entries: generic slow path)
-__device__ __forceinline__ float ell_w_at(const Cand &c, int s, int p) { return ((g_cfloat_p)c.ell_w4)[((size_t)(s >> 2) * c.N + p) * 4 + (s & 3)]; }
-__device__ __forceinline__ int ell_i_at(const Cand &c, int s, int p) { return ((g_cu16_p)c.ell_i4)[((size_t)(s >> 2) * c.N + p) * 4 + (s & 3)]; }
-
-// G~ xi for crop position p
-__device__ __forceinline__ double smooth_term(const Cand &c, const double *xv, int p)
-{
-    if (c.zmax <= ZREG) {
-        float w[ZREG]; RowIds ip;
-        load_row(c, p, w, ip);
-        return gather_row(c, xv, p, w, ip);
-    }
-    const int nnz = (int)(c.ell_meta[p] & 0xffffu);
-    double gx = 0;
-    for (int s = 0; s < nnz; s++) gx += (double)ell_w_at(c, s, p) * xv[6 + ell_i_at(c, s, p)];
-    return gx;
-}
-
-// psi only (line search, final energy).  Result broadcast to all threads.
+// psi only (final step check, start values).  Result broadcast to all threads.
 template <class L>
 __device__ __forceinline__ double eval_value(const Cand &c, int xo, int M)
 {
     const double *xv = SD + xo;
-    double psi = 0;
-    __builtin_amdgcn_s_setprio(0);
-    for (int p = c.p_lo + opaque_tid(); p < c.p_hi; p += L::WGS) {
-        double yv = c.crop_y[p];
-        uint32_t rc = c.crop_rc[p];
-        double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-        double S = u * u * xv[0] + v * v * xv[1] + 2 * (u * v) * xv[2] + 2 * u * xv[3] + 2 * v * xv[4] + xv[5];
-        if (M > 0) S += smooth_term(c, xv, p);
-        psi += softplus_neg(yv * S);
-    }
-    __builtin_amdgcn_s_setprio(2);
-    psi = block_sum<L::NWAVES>(psi, SD + L::RED);
-    if (c.wG > 1) {
-        double *tmp = SD + L::TMP;
-        __syncthreads();
-        if (threadIdx.x == 0) tmp[0] = psi;
-        __syncthreads();
-        wide_allreduce<L>(c, tmp, 1);
-        psi = tmp[0];
-        __syncthreads();
-    }
+    double tot[1];
+    run_pass<L, 1>(c, tot, [&](int p, bool active, double (&v)[1]) {
+        RunPix rp;
+        load_run(c, p, active, rp);
+        double S[SDSM_RUN];
+        poly_surface(rp, xv, S);
+        if (M > 0) smooth_add<1>(c, xv, p, active, chunk_entries(c, __builtin_amdgcn_readfirstlane(p)), S);
+        double ps = 0;
+#pragma unroll
+        for (int k = 0; k < SDSM_RUN; k++) if ((rp.pm >> k) & 1u) ps += softplus_neg(rp.y[k] * S[k]);
+        v[0] = ps;
+    });
+    if (c.wG > 1) wide_finish<L, 1>(c, tot);
+    double psi = tot[0];
     if (M > 0) {                                         // dsm.py:323-331
-        double s2 = 0;
-        for (int j = threadIdx.x; j < M; j += L::WGS) s2 += sqrt(xv[6 + j] * xv[6 + j] + c.epsilon);
-        s2 = block_sum<L::NWAVES>(s2, SD + L::RED);
-        double o2 = c.alpha * s2 - c.reg0;
+        const double s2 = wave_canon_sum(M, [&](int j) { return sqrt(xv[6 + j] * xv[6 + j] + c.epsilon); });
+        const double o2 = c.alpha * s2 - c.reg0;
         psi += o2 < 0 ? 0 : o2;
     }
     return uni(psi);                                     // every thread holds the same sum: scalar from here on (uniform control flow in the solver)
 }
 
-// Line search sweep: psi(x + t_k d) for LS_K step lengths t_k = t0 * 2^-k in ONE pass over the pixels.  S is linear in
-// the parameters, S(x + t d) = S(x) + t S(d): the row of G~ is fetched once, applied to xi and to d_xi (interleaved pairs
-// (x_j, d_j) at L::XT .. so one 16-byte LDS read serves both), and only the loss is evaluated LS_K times.
+// Line search sweep: psi(x + t_k d) for LS_K step lengths t_k = t0 * 2^-k in ONE pass over the runs.  S is linear in
+// the parameters, S(x + t d) = S(x) + t S(d): the entries of a run are fetched once, applied to xi and to d_xi (interleaved pairs
+// (x_j, d_j) at L::XT .. so one 16-byte LDS read serves both), and only the loss is evaluated LS_K times per pixel.
 template <class L>
 __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, double (&out)[LS_K])
 {
@@ -459,83 +571,48 @@ __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, doubl
     for (int i = tid; i < n; i += L::WGS) { xd[2 * i] = x[i]; xd[2 * i + 1] = d[i]; }
     __syncthreads();
     double ps[LS_K];
+    run_pass<L, LS_K>(c, ps, [&](int p, bool active, double (&v)[LS_K]) {
+        RunPix rp;
+        load_run(c, p, active, rp);
+        double S0[SDSM_RUN], Sd[SDSM_RUN];
+        {
+            const double uu = rp.u * rp.u, u2 = 2 * rp.u;
+            const double a0 = uu * xd[0] + u2 * xd[6] + xd[10], a1 = uu * xd[1] + u2 * xd[7] + xd[11];
+            const double b0 = u2 * xd[4] + 2 * xd[8], b1 = u2 * xd[5] + 2 * xd[9];
 #pragma unroll
-    for (int k = 0; k < LS_K; k++) ps[k] = 0;
-    const bool in_regs = c.zmax <= ZREG;
-    __builtin_amdgcn_s_setprio(0);
-    for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
-        const double yv = c.crop_y[p];
-        const uint32_t rc = c.crop_rc[p];
-        const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-        const double q0 = u * u, q1 = v * v, q2 = 2 * (u * v), q3 = 2 * u, q4 = 2 * v;
-        double S0 = q0 * xd[0] + q1 * xd[2] + q2 * xd[4] + q3 * xd[6] + q4 * xd[8] + xd[10];
-        double Sd = q0 * xd[1] + q1 * xd[3] + q2 * xd[5] + q3 * xd[7] + q4 * xd[9] + xd[11];
-        if (M > 0) {
-            if (in_regs) {
-                float w[ZREG]; RowIds ip;
-                load_row(c, p, w, ip);
-                const int q0g = __builtin_amdgcn_readfirstlane(p) & ~63;
+            for (int k = 0; k < SDSM_RUN; k++) {
+                const double vv = rp.v[k] * rp.v[k];
+                S0[k] = vv * xd[2] + rp.v[k] * b0 + a0;
+                Sd[k] = vv * xd[3] + rp.v[k] * b1 + a1;
+            }
+        }
+        if (M > 0) smooth_add2(c, xd, p, active, chunk_entries(c, __builtin_amdgcn_readfirstlane(p)), S0, Sd);
 #pragma unroll
-                for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) {
-                    if (q0g < c.gcount[j]) {
+        for (int k2 = 0; k2 < LS_K; k2++) v[k2] = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const double wv = (double)w[4 * j + k];
-                            const double *pr = xd + 2 * (6 + RID(ip, 4 * j + k));
-                            S0 += wv * pr[0]; Sd += wv * pr[1];
-                        }
-                    }
-                }
-            } else {
-                const int nnz = (int)(c.ell_meta[p] & 0xffffu);
-                for (int s2 = 0; s2 < nnz; s2++) {
-                    const double wv = (double)ell_w_at(c, s2, p);
-                    const double *pr = xd + 2 * (6 + ell_i_at(c, s2, p));
-                    S0 += wv * pr[0]; Sd += wv * pr[1];
+        for (int k = 0; k < SDSM_RUN; k++) {
+            __builtin_amdgcn_sched_barrier(0);                           // one pixel's four loss evaluations at a time (registers)
+            if ((rp.pm >> k) & 1u) {
+                const double a0 = rp.y[k] * S0[k], a1 = rp.y[k] * Sd[k];
+                double tk = t0;
+#pragma unroll
+                for (int k2 = 0; k2 < LS_K; k2++) {
+                    if (k2 == LS_K / 2) __builtin_amdgcn_sched_barrier(0);   // two independent loss evaluations in flight, not four (registers)
+                    v[k2] += softplus_neg(a0 + tk * a1); tk *= LS_BETA;
                 }
             }
         }
-        const double a0 = yv * S0, a1 = yv * Sd;
+    });
+    if (c.wG > 1) wide_finish<L, LS_K>(c, ps);
+    if (M > 0) {                                         // dsm.py:323-331
         double tk = t0;
 #pragma unroll
         for (int k = 0; k < LS_K; k++) {
-            if (k == LS_K / 2) __builtin_amdgcn_sched_barrier(0);       // two independent loss evaluations in flight, not four (registers)
-            const double t = a0 + tk * a1;
-            ps[k] += softplus_neg(t);
+            const double rs = wave_canon_sum(M, [&](int j) { const double xi = xd[2 * (6 + j)] + tk * xd[2 * (6 + j) + 1]; return sqrt(xi * xi + c.epsilon); });
+            const double o2 = c.alpha * rs - c.reg0;
+            ps[k] += o2 < 0 ? 0 : o2;
             tk *= LS_BETA;
         }
-    }
-    __builtin_amdgcn_s_setprio(2);
-    block_sum_vec<LS_K, L::NWAVES>(ps, SD + L::RED);
-    if (c.wG > 1) {
-        double *tmp = SD + L::TMP;
-        __syncthreads();
-        if (tid < LS_K) {
-            double v = 0;
-#pragma unroll
-            for (int k = 0; k < LS_K; k++) v = tid == k ? ps[k] : v;
-            tmp[tid] = v;
-        }
-        __syncthreads();
-        wide_allreduce<L>(c, tmp, LS_K);
-#pragma unroll
-        for (int k = 0; k < LS_K; k++) ps[k] = tmp[k];
-        __syncthreads();
-    }
-    if (M > 0) {                                         // dsm.py:323-331
-        double rs[LS_K];
-#pragma unroll
-        for (int k = 0; k < LS_K; k++) rs[k] = 0;
-        for (int j = tid; j < M; j += L::WGS) {
-            const double xj = xd[2 * (6 + j)], dj = xd[2 * (6 + j) + 1];
-            double tk = t0;
-#pragma unroll
-            for (int k = 0; k < LS_K; k++) { const double xi = xj + tk * dj; rs[k] += sqrt(xi * xi + c.epsilon); tk *= LS_BETA; }
-        }
-        block_sum_vec<LS_K, L::NWAVES>(rs, SD + L::RED);
-        const double reg_off = c.reg0;
-#pragma unroll
-        for (int k = 0; k < LS_K; k++) { const double o2 = c.alpha * rs[k] - reg_off; ps[k] += o2 < 0 ? 0 : o2; }
     }
 #pragma unroll
     for (int k = 0; k < LS_K; k++) out[k] = uni(ps[k]);
@@ -550,38 +627,27 @@ __device__ __forceinline__ double add_regulariser(const Cand &c, int M, double r
 {
     const double *xv = SD + L::X;
     double *g = SD + L::G, *Hp = hess_ptr<L>(c);
-    double s2 = 0;
     for (int j = threadIdx.x; j < M; j += L::WGS) {
         double xi = xv[6 + j], t3 = xi * xi, t2 = sqrt(t3 + c.epsilon);
-        s2 += t2;
         g[6 + j] += c.alpha * (xi / t2);
         double gd = c.alpha * (1 / t2 - t3 / (t2 * t2 * t2));
         gd = gd < 0 ? 0 : gd;
         gd += reg_mu * (c.alpha / t2 - gd);
         Hp[RBP[j] + j] += gd;
     }
-    s2 = block_sum<L::NWAVES>(s2, SD + L::RED);
+    const double s2 = wave_canon_sum(M, [&](int j) { return sqrt(xv[6 + j] * xv[6 + j] + c.epsilon); });
     double o2 = c.alpha * s2 - c.reg0;
     return o2 < 0 ? 0 : o2;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Polynomial part of one pixel's contribution to psi, gradient and Hessian, kept as MOMENTS of the coordinates: with
+// Polynomial part of the contributions to psi, gradient and Hessian, kept as MOMENTS of the coordinates: with
 // q = (u^2, v^2, 2uv, 2u, 2v, 1) the 6 gradient entries sum r q_a and the 21 Hessian entries sum d q_a q_b are small multiples
-// of sum r u^a v^b (a + b <= 2: 6 sums) and sum d u^a v^b (a + b <= 4: 15 sums) -- 22 per-lane accumulators instead of 28.
-//   m[0] psi; m[1..6] r * (1, u, v, u^2, uv, v^2); m[7..21] d * (1, u, v, u^2, uv, v^2, u^3, u^2 v, u v^2, v^3, u^4, u^3 v, u^2 v^2, u v^3, v^4)
+// of sum r u^a v^b (a + b <= 2: 6 sums) and sum d u^a v^b (a + b <= 4: 15 sums) -- 21 accumulators instead of 27.
+//   m[1..6] r * (1, u, v, u^2, uv, v^2); m[7..21] d * (1, u, v, u^2, uv, v^2, u^3, u^2 v, u v^2, v^3, u^4, u^3 v, u^2 v^2, u v^3, v^4)
+// (m[0] is not used).  The pixels of a run share u: its contribution to the moments is u^a times sum_k r_k v_k^b, sum_k d_k v_k^b.
 // ---------------------------------------------------------------------------------------------------------
 #define NMOM 22
-__device__ __forceinline__ void add_moments(double (&m)[NMOM], double phi, double r, double dc, double u, double v)
-{
-    const double uu = u * u, uv = u * v, vv = v * v;
-    m[0] += phi;
-    m[1] += r; m[2] += r * u; m[3] += r * v; m[4] += r * uu; m[5] += r * uv; m[6] += r * vv;
-    const double duu = dc * uu, duv = dc * uv, dvv = dc * vv;
-    m[7] += dc; m[8] += dc * u; m[9] += dc * v; m[10] += duu; m[11] += duv; m[12] += dvv;
-    m[13] += duu * u; m[14] += duu * v; m[15] += dvv * u; m[16] += dvv * v;
-    m[17] += duu * uu; m[18] += duu * uv; m[19] += duu * vv; m[20] += dvv * uv; m[21] += dvv * vv;
-}
 // gradient entry a = GF[a] * m[GM[a]]; Hessian entry t of the packed lower triangle (a >= b, t = a (a + 1) / 2 + b) = HF[t] * m[HM[t]]
 __device__ __forceinline__ double moment_grad(const double *tot, int a)
 {
@@ -602,215 +668,248 @@ __device__ __forceinline__ double moment_hess(const double *tot, int t)
     for (int k = 0; k < 21; k++) { mi = t == k ? hm[k] : mi; f = t == k ? hf[k] : f; }
     return f * tot[mi];
 }
-// totals of the NMOM sums over the workgroup -> LDS array tot[NMOM] (every thread may read any of them afterwards)
-template <class L>
-__device__ __forceinline__ void moments_total(const double (&m)[NMOM], double *tot)
-{
-    block_sum_scatter<NMOM, L::NWAVES>(m, SD + L::RED);
-    if (threadIdx.x < NMOM) tot[threadIdx.x] = sum_scatter_total<NMOM, L::NWAVES>(SD + L::RED, threadIdx.x);
-    __syncthreads();
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// ELLIPTICAL full evaluation (M = 0, n = 6): psi, 6 gradient entries and the 21 entries of the 6x6 Hessian are
-// per-lane register sums over the lane's pixels, reduced with wavefront shuffles + one LDS hop.
+// Fixed-point accumulation.  Sums over the pixels go through LDS atomics, and an integer add (ds_add_u64, 12 clocks per wavefront
+// instruction on scattered addresses) costs half of a floating-point one (ds_add_f64: 21; tools/microbench/lds_rates.hip) -- and
+// integer sums do not depend on the order of the additions, so a candidate's results do not depend on how its pixels were dealt to
+// lanes, wavefronts and workgroups.  A product a * b becomes an integer multiple of the unit 2^e by ONE instruction: fma(a, b, C)
+// with C = 1.5 * 2^(52 + e) rounds a * b to a multiple of 2^e and leaves it, offset by the bits of C, in the mantissa (valid for
+// |a b| < 2^(51 + e)); further products of the same entry are added by fma(a', b', s) before the one atomic.  e is chosen per
+// candidate from the bound on a term (|y| < 2^yexp from the setup kernel, weights <= 1, |u|, |v| <= 1) and the number of pixels,
+// so that a term has up to 48 bits (a run adds four of them before it rounds), and the sum of all terms stays below 2^62: for
+// N <= 2048 pixels the resolution of a term is 2^-48 of the largest possible one.
+// The bound follows the iteration: r = -y theta^ and d = y^2 kappa with theta^ = h / (1 + h), kappa = theta^ (1 - theta^) <= min(1/4,
+// theta^), and theta^ <= phi for t >= 0 (phi (1 + h) log(1 + h) / h >= theta^) while a pixel with t < 0 alone has phi >= ln 2: every
+// theta^ <= min(1, psi / ln 2).  An evaluation is given an upper bound of psi at its point (the value the line search just
+// computed there, the value at the start of a speculative step -- which is discarded if psi turns out larger --, the elliptical
+// energy at the start of the DSM solve) and scales its sums by 2^b >= that: on nearly separable regions, where psi and with it all
+// residuals go to 0 (SURVEY: theta -> infinity), the sums keep their relative resolution.
 // ---------------------------------------------------------------------------------------------------------
-template <class L>
-__device__ __forceinline__ double eval_full_ell(const Cand &c PROF_PARAM)
-{
-    long long pt = PROF_NOW();
-    const int tid = opaque_tid();
-    double *Hp = hess_ptr<L>(c), *g = SD + L::G;
-    const double *xv = SD + L::X;
-    double red[NMOM];
-#pragma unroll
-    for (int k = 0; k < NMOM; k++) red[k] = 0;
-    __builtin_amdgcn_s_setprio(0);
-    for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
-        const double yv = c.crop_y[p];
-        const uint32_t rc = c.crop_rc[p];
-        const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-        const double Sv = (u * u) * xv[0] + (v * v) * xv[1] + (2 * (u * v)) * xv[2] + (2 * u) * xv[3] + (2 * v) * xv[4] + xv[5];
-        double phi, r, dc;
-        loss_terms(yv, Sv, &phi, &r, &dc);
-        add_moments(red, phi, r, dc, u, v);
-    }
-    __builtin_amdgcn_s_setprio(2);
-    PROF_ADD(0, pt);
-    double *tot = SD + L::TMP;                           // TMP is free outside factor_solve
-    moments_total<L>(red, tot);
-    if (tid < 6) g[tid] = moment_grad(tot, tid);
-    if (tid < 21) Hp[tid] = moment_hess(tot, tid);       // packed lower triangle of a 6x6 matrix = the same enumeration order
-    double psi = tot[0];
-    __syncthreads();
-    if (c.wG > 1) {
-        double *tmp = SD + L::TMP;
-        if (tid == 0) tmp[0] = psi;
-        __syncthreads();
-        wide_allreduce<L>(c, Hp, 21, g, 6, tmp, 1);
-        psi = tmp[0];
-        __syncthreads();
-    }
-    PROF_ADD(2, pt);
-    return uni(psi);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Fixed-point accumulation of the sparse pass.  The per-pixel products go to the Hessian / gradient entries through LDS
-// atomics, and an integer add (ds_add_u64, 12 clocks per wavefront instruction on scattered addresses) costs half of a
-// floating-point one (ds_add_f64: 21; tools/microbench/lds_rates.hip) -- and integer sums do not depend on the order of
-// the additions, so a launch reproduces its results bit for bit.  A product a * b becomes an integer multiple of the unit
-// 2^e by ONE instruction: fma(a, b, C) with C = 1.5 * 2^(52 + e) rounds a * b to a multiple of 2^e and leaves it, offset by
-// the bits of C, in the mantissa (valid for |a b| < 2^(51 + e)).  e is chosen per candidate from the bound on a term (|y| <
-// 2^yexp from the setup kernel, weights <= 1, |u|, |v| <= 1) and the number of pixels, so that a term has up to 50 bits and
-// the sum of all terms stays below 2^62: for N <= 2048 pixels the resolution of a term is that of a double.
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fx_exponents(int yexp, int N, int *hh, int *gh)
+__device__ __forceinline__ void fx_exponents(int yexp, int N, double psi_bound, int *hh, int *gh)
 {
     const int lg = N > 1 ? 32 - __builtin_clz((unsigned)(N - 1)) : 0;       // ceil(log2 N)
-    const int bits = 61 - lg < 50 ? 61 - lg : 50;
-    const int eh = 2 * yexp - 1 - bits, eg = yexp - bits;                   // Hessian terms < 2^(2 yexp - 1), gradient terms < 2^yexp
+    const int bits = 59 - lg < 48 ? 59 - lg : 48;
+    int b = 0;                                                               // theta^ <= 2^b
+    const double tb = psi_bound * 1.442696484;                               // (a little more than 1 / ln 2: rounding of the psi sums)
+    if (tb < 1.0) {                                                          // (false for NaN / infinity: no bound)
+        int ex = ((__double2hiint(tb) >> 20) & 0x7ff) - 1022;                // tb < 2^ex
+        b = ex < -400 || tb <= 0 ? -400 : ex;
+    }
+    const int eh = 2 * yexp + (b < -1 ? b : -1) - bits, eg = yexp + b - bits;   // Hessian terms < 2^(2 yexp + min(b, -1)), gradient terms < 2^(yexp + b)
     *hh = ((1075 + eh) << 20) | 0x80000;
     *gh = ((1075 + eg) << 20) | 0x80000;
 }
-__device__ __forceinline__ void fx_add(double *addr, double a, double b, int chi)
+__device__ __forceinline__ double fx_const(int chi) { return __hiloint2double(chi, 0); }
+// s = C + (sum of products, rounded to the unit): add its integer value to *addr
+__device__ __forceinline__ void fx_commit(double *addr, double s, int chi)
 {
-    const double s = fma(a, b, __hiloint2double(chi, 0));
     const unsigned long long v = ((unsigned long long)(unsigned)(__double2hiint(s) - chi) << 32) | (unsigned)__double2loint(s);
     atomicAdd(reinterpret_cast<unsigned long long *>(addr), v);
 }
+__device__ __forceinline__ void fx_add(double *addr, double a, double b, int chi) { fx_commit(addr, fma(a, b, fx_const(chi)), chi); }
 __device__ __forceinline__ double fx_unit(int chi) { return __hiloint2double((chi & 0x7ff00000) - (52 << 20), 0); }
 __device__ __forceinline__ double fx_get(double raw, double unit) { return (double)__double_as_longlong(raw) * unit; }
 
 // ---------------------------------------------------------------------------------------------------------
-// SPARSE full evaluation (n > 40): per-pixel products added into the packed Hessian in LDS (ds_add_f64).
+// Full evaluation: psi, gradient and (approximate) Hessian at L::X.  M = 0: the elliptical model (the entries of the runs are
+// not touched).
 // ---------------------------------------------------------------------------------------------------------
 template <class L>
-__device__ __forceinline__ double eval_full_sparse(const Cand &c, int M, double reg_mu PROF_PARAM)
+__device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu, double psi_bound PROF_PARAM)
 {
     long long pt = PROF_NOW();
     const int tid = opaque_tid();
     const int n = 6 + M;
+    int fxh_hi, fxg_hi;                                  // high words of the constants 1.5 * 2^(52 + e), Hessian / gradient scale of THIS evaluation
+    fx_exponents(c.yexp, c.N, psi_bound, &fxh_hi, &fxg_hi);
+    fxh_hi = uni(fxh_hi); fxg_hi = uni(fxg_hi);
     double *Hp = hess_ptr<L>(c), *g = SD + L::G;
     const double *xv = SD + L::X;
     const int *rbp = RBP;
-    double *tot = SD + L::TMP;                           // TMP is free outside factor_solve
-    for (int e = tid; e < c.env_size; e += L::WGS) Hp[e] = 0;
+    unsigned long long *msl = reinterpret_cast<unsigned long long *>(SD + L::MS);
+    const int esz = M > 0 ? c.env_size : 21;
+    for (int e = tid; e < esz; e += L::WGS) Hp[e] = 0;
     for (int i = tid; i < n; i += L::WGS) g[i] = 0;
+    for (int e = tid; e < 21 * NSLOT; e += L::WGS) msl[e] = 0;
     __syncthreads();
-    const int zm = M > 0 ? c.zmax : 0;
-    const bool in_regs = zm <= ZREG;
-    // One loop over the pixels; the row of G~ is loaded TWICE per pixel -- for S, and again after the loss terms for the atomics
-    // (served by the caches) -- instead of being held in 42 registers across the loss evaluation: the kernel runs three
-    // wavefronts per SIMD (168 registers).
-    {
-        int rbt[6];                                      // the 6 dense theta rows (uniform)
+    int rbt[6];                                          // the 6 dense theta rows (uniform)
 #pragma unroll
-        for (int b = 0; b < 6; b++) rbt[b] = __builtin_amdgcn_readfirstlane(rbp[M + b]);
-        double red[NMOM];                                // psi and the coordinate moments of r and d (add_moments)
+    for (int b = 0; b < 6; b++) rbt[b] = M > 0 ? __builtin_amdgcn_readfirstlane(rbp[M + b]) : 0;
+    double *ms = reinterpret_cast<double *>(msl + (tid & (NSLOT - 1)));     // this lane's slot: moment m at ms[(m - 1) * NSLOT]
+    const bool hfast = c.hzmax <= HZREG;
+    double tot[1];
+    run_pass<L, 1>(c, tot, [&](int p, bool active, double (&pv)[1]) {
+        RunPix rp;
+        load_run(c, p, active, rp);
+        const int kh = M > 0 ? chunk_entries(c, __builtin_amdgcn_readfirstlane(p)) : 0;
+        double S[SDSM_RUN];
+        poly_surface(rp, xv, S);
+        if (M > 0) smooth_add<1>(c, xv, p, active, kh, S);
+        double r[SDSM_RUN], d[SDSM_RUN], psum = 0;
 #pragma unroll
-        for (int k = 0; k < NMOM; k++) red[k] = 0;
-        __builtin_amdgcn_s_setprio(0);
-        for (int p = c.p_lo + tid; p < c.p_hi; p += L::WGS) {
-            FINE_START();
-            const double yv = c.crop_y[p];
-            const uint32_t rc = c.crop_rc[p];
-            const double u = ((double)(rc >> 16) - c.rmid) * c.inv_hr, v = ((double)(rc & 0xffffu) - c.cmid) * c.inv_hc;
-            double Sv = (u * u) * xv[0] + (v * v) * xv[1] + (2 * (u * v)) * xv[2] + (2 * u) * xv[3] + (2 * v) * xv[4] + xv[5];
-            FINE_ADD(8);
-            Sv += smooth_term(c, xv, p);
-            FINE_ADD(9);
-            double phi, r, dc;
-            loss_terms(yv, Sv, &phi, &r, &dc);
-            add_moments(red, phi, r, dc, u, v);
-            FINE_ADD(10);
-            if (dc != 0 || r != 0) {
-                const double q[6] = {u * u, v * v, 2 * (u * v), 2 * u, 2 * v, 1.0};
-                const uint32_t meta = c.ell_meta[p];
-                const int nnz = (int)(meta & 0xffffu), hnz = (int)(meta >> 16);
-                if (in_regs) {
-                    int p2 = p;
-                    asm volatile("" : "+v"(p2));          // (a second load, not the first one kept alive)
-                    float w[ZREG]; RowIds ip;
-                    load_row(c, p2, w, ip);
-                    const int q0 = __builtin_amdgcn_readfirstlane(p) & ~63;
+        for (int k = 0; k < SDSM_RUN; k++) {
+#ifdef SDSM_LOSS_SERIAL
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            if ((k & 1) == 0) __builtin_amdgcn_sched_barrier(0);     // two independent loss evaluations in flight, not four (registers)
+#endif
+            r[k] = 0; d[k] = 0;
+            if ((rp.pm >> k) & 1u) { double ph; loss_terms(rp.y[k], S[k], &ph, &r[k], &d[k]); psum += ph; }
+        }
+        pv[0] = psum;
+        if (!active) return;
+        // moments of the run: u^a * sum_k (r_k | d_k) v_k^b
+        const double u = rp.u, uu = u * u;
+        double R0 = 0, R1 = 0, R2 = 0, D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0;
+        bool anynz = false;
 #pragma unroll
-                    for (int j = SDSM_ELL_GROUPS_REG - 1; j >= 0; j--) {          // (the leading entries, groups 0 .. 2, are used again below)
-                        if (q0 < c.gcount[j]) {
+        for (int k = 0; k < SDSM_RUN; k++) {
+            const double vk = rp.v[k], vv = vk * vk, dvv = d[k] * vv;
+            R0 += r[k]; R1 = fma(r[k], vk, R1); R2 = fma(r[k], vv, R2);
+            D0 += d[k]; D1 = fma(d[k], vk, D1); D2 += dvv; D3 = fma(dvv, vk, D3); D4 = fma(dvv, vv, D4);
+            anynz = anynz || d[k] != 0 || r[k] != 0;
+        }
+        {
+            const int cg = fxg_hi, ch = fxh_hi;
+            const double u3 = uu * u, u4 = uu * uu;
+            fx_add(ms + 0 * NSLOT, R0, 1.0, cg); fx_add(ms + 1 * NSLOT, R0, u, cg); fx_add(ms + 2 * NSLOT, R1, 1.0, cg);
+            fx_add(ms + 3 * NSLOT, R0, uu, cg); fx_add(ms + 4 * NSLOT, R1, u, cg); fx_add(ms + 5 * NSLOT, R2, 1.0, cg);
+            fx_add(ms + 6 * NSLOT, D0, 1.0, ch); fx_add(ms + 7 * NSLOT, D0, u, ch); fx_add(ms + 8 * NSLOT, D1, 1.0, ch);
+            fx_add(ms + 9 * NSLOT, D0, uu, ch); fx_add(ms + 10 * NSLOT, D1, u, ch); fx_add(ms + 11 * NSLOT, D2, 1.0, ch);
+            fx_add(ms + 12 * NSLOT, D0, u3, ch); fx_add(ms + 13 * NSLOT, D1, uu, ch); fx_add(ms + 14 * NSLOT, D2, u, ch); fx_add(ms + 15 * NSLOT, D3, 1.0, ch);
+            fx_add(ms + 16 * NSLOT, D0, u4, ch); fx_add(ms + 17 * NSLOT, D1, u3, ch); fx_add(ms + 18 * NSLOT, D2, uu, ch); fx_add(ms + 19 * NSLOT, D3, u, ch);
+            fx_add(ms + 20 * NSLOT, D4, 1.0, ch);
+        }
+        if (M == 0 || !anynz) return;
+        // xi part.  Gradient: every entry of the run; Hessian: its leading entries (kept in registers as they pass by)
+        f32x4 lw[HZREG];
+        uint32_t lim[HZREG];
 #pragma unroll
-                            for (int k = 0; k < 4; k++)
-                                if (4 * j + k < nnz) fx_add(&g[6 + RID(ip, 4 * j + k)], r, (double)w[4 * j + k], c.fxg_hi);   // exact gradient: every entry
-                        }
-                    }
-                    FINE_ADD(11);
-                    if (c.hzmax <= HZREG) {
-                        int rbs[HZREG];                                                      // row bases of the leading entries
+        for (int a = 0; a < HZREG; a++) { lw[a].x = 0.f; lw[a].y = 0.f; lw[a].z = 0.f; lw[a].w = 0.f; lim[a] = 0; }
+        int p2 = p;
+        asm volatile("" : "+v"(p2));                      // (a second load of the entries, not the first one kept alive across the loss evaluation)
+        const double cgd = fx_const(fxg_hi);
+        auto grad_entry = [&](const f32x4 &w, uint32_t im) {
+            double acc = fma(r[0], (double)w.x, cgd);
+            acc = fma(r[1], (double)w.y, acc); acc = fma(r[2], (double)w.z, acc); acc = fma(r[3], (double)w.w, acc);
+            fx_commit(&g[6 + (int)(im & 0xffffu)], acc, fxg_hi);
+        };
+        static_assert(HZREG % EBATCH == 0, "the leading entries are taken from whole batches");
 #pragma unroll
-                        for (int a = 0; a < HZREG; a++) rbs[a] = a < hnz ? rbp[RID(ip, a)] : 0;
+        for (int jb = 0; jb < HZREG; jb += EBATCH) {          // the first batch(es) in straight-line code: they include the HZREG leading entries
+            f32x4 w[EBATCH];
+            uint32_t im[EBATCH];
 #pragma unroll
-                        for (int a = 0; a < HZREG; a++) {                                    // approximate Hessian: leading entries
-                            if (a < hnz) {
-                                const double dwa = dc * (double)w[a];
-                                const int ia = RID(ip, a);
+            for (int t = 0; t < EBATCH; t++) {
+                w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
+                if (jb + t < kh) { w[t] = c.ell_w4[(size_t)(jb + t) * c.NR + p2]; im[t] = c.ell_im[(size_t)(jb + t) * c.NR + p2]; }
+            }
 #pragma unroll
-                                for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);      // theta rows, column xi_ia
+            for (int t = 0; t < EBATCH; t++) {
+                if (jb + t < kh) {
+                    if (jb + t < rp.nnz) grad_entry(w[t], im[t]);
+                    if (jb + t < HZREG) { lw[jb + t] = w[t]; lim[jb + t] = im[t]; }
+                }
+            }
+        }
+        for (int j0 = HZREG; j0 < kh; j0 += EBATCH) {
+            f32x4 w[EBATCH];
+            uint32_t im[EBATCH];
 #pragma unroll
-                                for (int b = 0; b <= a; b++) fx_add(&Hp[rbs[a] + RID(ip, b)], dwa, (double)w[b], c.fxh_hi);   // leading entries are in ascending column order
-                            }
-                        }
-                    } else {
-                        for (int a = 0; a < hnz; a++) {
-                            const double dwa = dc * (double)ell_w_at(c, a, p);
-                            const int ia = ell_i_at(c, a, p);
-                            for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);
-                            for (int b = 0; b <= a; b++) {
-                                const int ib = ell_i_at(c, b, p);
-                                fx_add(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa, (double)ell_w_at(c, b, p), c.fxh_hi);
-                            }
-                        }
-                    }
-                } else {
-                    for (int a = 0; a < nnz; a++) {
-                        const double wa = (double)ell_w_at(c, a, p), dwa = dc * wa;
-                        const int ia = ell_i_at(c, a, p);
-                        fx_add(&g[6 + ia], r, wa, c.fxg_hi);
-                        if (a >= hnz) continue;
-                        for (int b = 0; b < 6; b++) fx_add(&Hp[rbt[b] + ia], dwa, q[b], c.fxh_hi);
-                        for (int b = 0; b <= a; b++) {
-                            const int ib = ell_i_at(c, b, p);
-                            fx_add(&Hp[ia >= ib ? rbp[ia] + ib : rbp[ib] + ia], dwa, (double)ell_w_at(c, b, p), c.fxh_hi);
+            for (int t = 0; t < EBATCH; t++) {
+                w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
+                if (j0 + t < kh) { w[t] = c.ell_w4[(size_t)(j0 + t) * c.NR + p2]; im[t] = c.ell_im[(size_t)(j0 + t) * c.NR + p2]; }
+            }
+#pragma unroll
+            for (int t = 0; t < EBATCH; t++) if (j0 + t < kh && j0 + t < rp.nnz) grad_entry(w[t], im[t]);
+        }
+        const double chd = fx_const(fxh_hi);
+        const double v2[SDSM_RUN] = {rp.v[0] * rp.v[0], rp.v[1] * rp.v[1], rp.v[2] * rp.v[2], rp.v[3] * rp.v[3]};
+        const double u2 = 2 * u;
+        // one leading entry a (column ia, the four pixels' weights masked by "leading for that pixel"): the six theta rows through
+        // three sums over the run (its pixels share u), then the leading entries b <= a
+        auto theta_rows = [&](int ia, const double (&dw)[SDSM_RUN]) {
+            const double m0 = (dw[0] + dw[1]) + (dw[2] + dw[3]);
+            const double m1 = fma(dw[3], rp.v[3], fma(dw[2], rp.v[2], fma(dw[1], rp.v[1], dw[0] * rp.v[0])));
+            const double m2 = fma(dw[3], v2[3], fma(dw[2], v2[2], fma(dw[1], v2[1], dw[0] * v2[0])));
+            fx_add(&Hp[rbt[0] + ia], m0, uu, fxh_hi); fx_add(&Hp[rbt[1] + ia], m2, 1.0, fxh_hi); fx_add(&Hp[rbt[2] + ia], m1, u2, fxh_hi);
+            fx_add(&Hp[rbt[3] + ia], m0, u2, fxh_hi); fx_add(&Hp[rbt[4] + ia], m1, 2.0, fxh_hi); fx_add(&Hp[rbt[5] + ia], m0, 1.0, fxh_hi);
+        };
+        if (hfast) {
+            int rbs[HZREG];                                                          // row bases of the leading entries
+#pragma unroll
+            for (int a = 0; a < HZREG; a++) {
+                rbs[a] = a < rp.hz ? rbp[lim[a] & 0xffffu] : 0;
+                const unsigned la = lim[a] >> 16;                                    // weights of pixels for which the entry is not a leading one: 0
+                lw[a].x = (la & 1u) ? lw[a].x : 0.f; lw[a].y = (la & 2u) ? lw[a].y : 0.f; lw[a].z = (la & 4u) ? lw[a].z : 0.f; lw[a].w = (la & 8u) ? lw[a].w : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < HZREG; a++) {
+                if (a < rp.hz) {
+                    const double dw[SDSM_RUN] = {d[0] * (double)lw[a].x, d[1] * (double)lw[a].y, d[2] * (double)lw[a].z, d[3] * (double)lw[a].w};
+                    theta_rows((int)(lim[a] & 0xffffu), dw);
+#pragma unroll
+                    for (int b = 0; b <= a; b++) {                                   // leading entries are in ascending column order
+                        if ((lim[a] >> 16) & (lim[b] >> 16)) {                       // some pixel couples the two
+                            double acc = fma(dw[0], (double)lw[b].x, chd);
+                            acc = fma(dw[1], (double)lw[b].y, acc); acc = fma(dw[2], (double)lw[b].z, acc); acc = fma(dw[3], (double)lw[b].w, acc);
+                            fx_commit(&Hp[rbs[a] + (int)(lim[b] & 0xffffu)], acc, fxh_hi);
                         }
                     }
                 }
             }
-            FINE_ADD(12);
+        } else {                                             // runs with more leading entries than the registers hold: from memory
+            for (int a = 0; a < rp.hz; a++) {
+                const f32x4 wa = c.ell_w4[(size_t)a * c.NR + p2];
+                const uint32_t ima = c.ell_im[(size_t)a * c.NR + p2];
+                const unsigned la = ima >> 16;
+                const int ia = (int)(ima & 0xffffu), rba = rbp[ia];
+                const double dw[SDSM_RUN] = {(la & 1u) ? d[0] * (double)wa.x : 0.0, (la & 2u) ? d[1] * (double)wa.y : 0.0,
+                                             (la & 4u) ? d[2] * (double)wa.z : 0.0, (la & 8u) ? d[3] * (double)wa.w : 0.0};
+                theta_rows(ia, dw);
+                for (int b = 0; b <= a; b++) {
+                    const f32x4 wb = c.ell_w4[(size_t)b * c.NR + p2];
+                    const uint32_t imb = c.ell_im[(size_t)b * c.NR + p2];
+                    const unsigned lb = imb >> 16;
+                    if (!(la & lb)) continue;
+                    double acc = fma(dw[0], (lb & 1u) ? (double)wb.x : 0.0, chd);
+                    acc = fma(dw[1], (lb & 2u) ? (double)wb.y : 0.0, acc); acc = fma(dw[2], (lb & 4u) ? (double)wb.z : 0.0, acc); acc = fma(dw[3], (lb & 8u) ? (double)wb.w : 0.0, acc);
+                    fx_commit(&Hp[rba + (int)(imb & 0xffffu)], acc, fxh_hi);
+                }
+            }
         }
-        __builtin_amdgcn_s_setprio(2);
-        PROF_ADD(0, pt);
-        moments_total<L>(red, tot);                      // (its barriers: every atomic of the pass has landed)
-    }
-    {
-        const double uh = fx_unit(c.fxh_hi), ug = fx_unit(c.fxg_hi);
-        for (int e = tid; e < c.env_size; e += L::WGS) Hp[e] = fx_get(Hp[e], uh);
-        for (int i = 6 + tid; i < n; i += L::WGS) g[i] = fx_get(g[i], ug);
+    });
+    PROF_ADD(0, pt);
+    // totals of the moment slots (integers: any order), as raw integers for the exchange of a workgroup group
+    unsigned long long *mraw = reinterpret_cast<unsigned long long *>(SD + L::RED);
+    double *tot22 = SD + L::RED + 32;
+    if (tid < 21) {
+        unsigned long long sacc = 0;
+        for (int i = 0; i < NSLOT; i++) sacc += msl[tid * NSLOT + i];
+        mraw[tid] = sacc;
     }
     __syncthreads();
-    if (tid < 6) g[tid] = moment_grad(tot, tid);
+    if (c.wG > 1) wide_finish<L, 1>(c, tot, Hp, M > 0 ? c.env_size : 0, g + 6, M, reinterpret_cast<double *>(mraw), 21);
+    {
+        const double uh = fx_unit(fxh_hi), ug = fx_unit(fxg_hi);
+        if (M > 0) {
+            for (int e = tid; e < c.env_size; e += L::WGS) Hp[e] = fx_get(Hp[e], uh);
+            for (int i = 6 + tid; i < n; i += L::WGS) g[i] = fx_get(g[i], ug);
+        }
+        if (tid < 21) tot22[1 + tid] = fx_get(reinterpret_cast<double *>(mraw)[tid], tid < 6 ? ug : uh);
+    }
+    __syncthreads();
+    if (tid < 6) g[tid] = moment_grad(tot22, tid);
     if (tid < 21) {
-        int a = 0;
-        while ((a + 1) * (a + 2) / 2 <= tid) a++;
-        Hp[rbp[M + a] + M + (tid - a * (a + 1) / 2)] = moment_hess(tot, tid);   // theta-theta block: columns M .. M + a of row M + a
+        if (M == 0) Hp[tid] = moment_hess(tot22, tid);           // packed lower triangle of a 6x6 matrix = the same enumeration order
+        else {
+            int a = 0;
+            while ((a + 1) * (a + 2) / 2 <= tid) a++;
+            Hp[rbp[M + a] + M + (tid - a * (a + 1) / 2)] = moment_hess(tot22, tid);   // theta-theta block: columns M .. M + a of row M + a
+        }
     }
     double psi = tot[0];
     __syncthreads();
-    if (c.wG > 1) {                                      // partial Hessian / gradient / psi of this member's slice -> totals
-        double *tmp = SD + L::TMP;
-        if (tid == 0) tmp[0] = psi;
-        __syncthreads();
-        wide_allreduce<L>(c, Hp, c.env_size, g, n, tmp, 1);
-        psi = tmp[0];
-        __syncthreads();
-    }
     if (M > 0) psi += add_regulariser<L>(c, M, reg_mu);
     __syncthreads();
     PROF_ADD(2, pt);
@@ -1111,9 +1210,7 @@ __device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in,
     __syncthreads();
     PROF_ADD(14, pf);
     if (failed) return failed;
-    double l2 = 0;
-    for (int i = tid; i < n; i += L::WGS) l2 += yrow[i] * yrow[i];
-    l2 = block_sum<L::NWAVES>(l2, SD + L::RED);
+    const double l2 = wave_canon_sum(n, [&](int i) { return yrow[i] * yrow[i]; });     // (the same bits for every workgroup size)
     // back substitution L^T z = yrow: by one wavefront in registers when n <= 256 (back_substitute_wave), else blocked like the
     // factorisation (one barrier per panel)
     if (L::NMAX <= 128 || n <= 256) {
@@ -1184,7 +1281,7 @@ __device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in,
 #define MU_DECAY 0.5
 #define MU_MIN 1e-3
 template <class L>
-__device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, double *psi_out, int *iters_out, int *ev_value, int *ev_full PROF_PARAM)
+__device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, double psi_start_bound, double *psi_out, int *iters_out, int *ev_value, int *ev_full PROF_PARAM)
 {
     enum { EV_STEP = 0, EV_SPEC = 1, EV_RETRY = 2, EV_CHECK = 3 };
     const int tid = opaque_tid(), n = 6 + M;
@@ -1192,10 +1289,9 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
     int status = 1, iters = 0, why = EV_STEP, retries = 0;
     double mu = M > 0 ? 1.0 : 0.0, mu_spec = 0, tprev = 0, tau = 0;
     double psi = NAN, f = NAN, lam2 = 0;                     // f, lam2 describe x (kept across a speculative evaluation)
+    double bound = uni(psi_start_bound);                     // an upper bound of psi at the point of the next evaluation (fx_exponents); infinity: none
     for (;;) {
-        double pe;
-        if (M == 0) pe = eval_full_ell<L>(c PROF_ARG);
-        else pe = eval_full_sparse<L>(c, M, why == EV_SPEC ? mu_spec : mu PROF_ARG);
+        const double pe = eval_full<L>(c, M, why == EV_SPEC ? mu_spec : mu, bound PROF_ARG);
         (*ev_full)++;
         long long pt = PROF_NOW();
         bool line = false;
@@ -1209,6 +1305,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
                 line = true; t0 = 0.5;
             }
         } else if (why != EV_RETRY) psi = pe;
+        bound = uni(psi);                                    // evaluations at x again (larger shift, true curvature) and the speculative x + d, which only counts if psi does not grow
         if (!line) {
             if (why != EV_RETRY) {
                 if (iters >= max_iters) { status = 1; break; }
@@ -1276,6 +1373,7 @@ __device__ __forceinline__ int newton(const Cand &c, int M, int max_iters, doubl
         }
         PROF_ADD(4, pt);
         if (!accepted) { status = 1; break; }               // stalled; psi still is the value at x
+        bound = uni(fbest / c.scale);                        // psi(x + tbest d) as the sweep computed it
         for (int i = tid; i < n; i += L::WGS) x[i] += tbest * d[i];
         __syncthreads();
         tprev = uni(tbest);
@@ -1376,27 +1474,27 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     }
 
     Cand c;
-    c.N = cd.N; c.zmax = Mfull > 0 ? st.zmax : 0; c.hzmax = Mfull > 0 ? st.hzmax : 0; c.env_size = 21;
-    c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr; c.wtimeout = P.wide_timeout;
+    c.N = cd.N; c.NR = st.NR; c.hzmax = Mfull > 0 ? st.hzmax : 0; c.env_size = 21;
+    c.p_lo = 0; c.p_hi = st.NR; c.wg = 0; c.wG = 1; c.wpool = nullptr; c.wtimeout = P.wide_timeout;
     if (WIDE) {
         c.wG = cd.wide_g; c.wg = wg; c.wpool = P.wide_pool + cd.wide_off;
-        const int chunk = (((cd.N + c.wG - 1) / c.wG) + 63) & ~63;           // slices start at multiples of 64 (row-group logic of load_row)
-        c.p_lo = wg * chunk < cd.N ? wg * chunk : cd.N;
-        c.p_hi = c.p_lo + chunk < cd.N ? c.p_lo + chunk : cd.N;
+        const int sup = 64 * SDSM_SUPER;                                     // slices are whole super-chunks (run_pass: the order of the psi sums)
+        const int chunk = (((st.NR + c.wG - 1) / c.wG) + sup - 1) / sup * sup;
+        c.p_lo = wg * chunk < st.NR ? wg * chunk : st.NR;
+        c.p_hi = c.p_lo + chunk < st.NR ? c.p_lo + chunk : st.NR;
     }
     if (tid == 0) { *WIDE_PHASE = 0; *WIDE_OPS = 0; }
     if (WIDE && wg == 0) {                                               // cleared here: the members set bits at the very end, after many group barriers
         uint32_t *mk0 = masks + cd.mask_off;
         for (int i = tid; i < (cd.h * cd.w + 31) / 32; i += L::WGS) mk0[i] = 0;
     }
-    c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
-    c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
-#pragma unroll
-    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = Mfull > 0 ? st.gcount[j] : 0;
+    c.crop_y2 = (g_cf64x2_p)(P.crop_y + cd.run_off * SDSM_RUN); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.run_off); c.meta = (g_cu32_p)(P.run_meta + cd.run_off);
+    c.aux = (g_cu32_p)(P.run_aux + cd.run_off);
+    c.ell_im = (g_cu32_p)(P.ell_im + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(reinterpret_cast<const f32x4 *>(P.ell_w) + cd.ell_off);
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
     c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * Mfull;   // (only read by passes with M = Mfull > 0)
-    fx_exponents(st.yexp, cd.N, &c.fxh_hi, &c.fxg_hi);
+    c.yexp = st.yexp;
     // local frame: centre of the bounding box, half extents
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
@@ -1417,7 +1515,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     //      not optimal, objects.py:337-355), 2 deformable shape model (objects.py:394-410) ---------------
     for (int i = tid; i < NMAX; i += L::WGS) x[i] = 0;
     __syncthreads();
-    double psi_ell = INFINITY, psi_final = NAN;
+    double psi_ell = INFINITY, psi_final = NAN, vinit_keep = INFINITY;
     bool have = false, fallback = false;
     double keep[6] = {0, 0, 0, 0, 0, 0};
     int s_prev = 0;
@@ -1453,6 +1551,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
             double vinit = eval_value<L>(c, L::XT, 0);
             ev_value++;
             if (vinit > psi_ell) continue;                                      // objects.py:341-342
+            vinit_keep = uni(vinit);
             if (tid < 6) x[tid] = xt[tid];
             __syncthreads();
         } else if (phase == 2) {
@@ -1477,7 +1576,10 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
             __syncthreads();
         }
         double psi; int its;
-        int s = newton<L>(c, M, P.max_iters, &psi, &its, &ev_value, &ev_full PROF_ARG);
+        // what is known about psi at the start: nothing (zeros: N ln 2), the value just computed (moment initialisation), the elliptical
+        // energy (the DSM solve starts at [theta_ell, 0]: the same surface, the regulariser is 0 there)
+        const double start_bound = phase == 0 ? INFINITY : (phase == 1 ? vinit_keep : (have ? psi_ell : INFINITY));
+        int s = newton<L>(c, M, P.max_iters, start_bound, &psi, &its, &ev_value, &ev_full PROF_ARG);
         tid = opaque_tid();
 #ifdef SDSM_PROFILE
         if (phase < 2) { prof_acc[6] = PROF_NOW() - prof_t_start; }
@@ -1522,17 +1624,27 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     int onb = 0;
     if (status_final != SDSM_CAND_ERROR) {
         __builtin_amdgcn_s_setprio(0);
-        for (int p = c.p_lo + opaque_tid(); p < c.p_hi; p += L::WGS) {
-            uint32_t rc = c.crop_rc[p];
-            int pr = rc >> 16, pc = rc & 0xffffu;
-            double u = ((double)pr - c.rmid) * c.inv_hr, v = ((double)pc - c.cmid) * c.inv_hc;
-            double Sv = u * u * x[0] + v * v * x[1] + 2 * (u * v) * x[2] + 2 * u * x[3] + 2 * v * x[4] + x[5];
-            if (Mfull > 0) Sv += smooth_term(c, x, p);
-            if (Sv > 0) {
-                int bit = (pr - cd.r0) * cd.w + (pc - cd.c0);
-                atomicOr(&mk[bit >> 5], 1u << (bit & 31));
-                rmin = pr < rmin ? pr : rmin; rmax = pr > rmax ? pr : rmax;
-                cmin = pc < cmin ? pc : cmin; cmax = pc > cmax ? pc : cmax;
+        for (int pb = c.p_lo + (opaque_tid() & ~63); pb < c.p_hi; pb += L::WGS) {
+            const int p = pb + (int)(threadIdx.x & 63);
+            const bool active = p < c.p_hi;
+            RunPix rp;
+            load_run(c, p, active, rp);
+            double Sv[SDSM_RUN];
+            poly_surface(rp, x, Sv);
+            if (Mfull > 0) smooth_add<1>(c, x, p, active, chunk_entries(c, pb), Sv);
+            if (active) {
+                const uint32_t rc = c.crop_rc[p];
+                const int pr = rc >> 16, pc0 = rc & 0xffffu;
+#pragma unroll
+                for (int k = 0; k < SDSM_RUN; k++) {
+                    if (((rp.pm >> k) & 1u) && Sv[k] > 0) {
+                        const int pc = pc0 + k;
+                        const int bit = (pr - cd.r0) * cd.w + (pc - cd.c0);
+                        atomicOr(&mk[bit >> 5], 1u << (bit & 31));
+                        rmin = pr < rmin ? pr : rmin; rmax = pr > rmax ? pr : rmax;
+                        cmin = pc < cmin ? pc : cmin; cmax = pc > cmax ? pc : cmax;
+                    }
+                }
             }
         }
         __builtin_amdgcn_s_setprio(2);
@@ -1592,7 +1704,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
 
 // ---------------------------------------------------------------------------------------------------------
 // Point evaluation for parity tests (sdsm_batch_eval): psi, gradient and the polynomial block of the Hessian at
-// caller-given parameters, computed by the SAME evaluators the solver uses (eval_full_ell / eval_full_sparse: loss_terms;
+// caller-given parameters, computed by the SAME evaluators the solver uses (eval_full: loss_terms;
 // eval_value: softplus_neg) on the crops and G~ rows a previous sdsm_batch_launch left in the workspace.  Parameters and
 // results are in the reference's full-image-normalised basis (dsm.py:49-54); the evaluators work in the candidate's local
 // basis theta_local = R theta (reparam), so grad = R^T grad_local and H = R^T H_local R.
@@ -1614,15 +1726,14 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     if (!(n <= NMAX && efull <= EMAX)) return;
     if (GLOBALH && cd.hglob_off < 0) return;
     Cand c;
-    c.N = cd.N; c.zmax = M > 0 ? st.zmax : 0; c.hzmax = M > 0 ? st.hzmax : 0; c.env_size = efull;
-    c.p_lo = 0; c.p_hi = cd.N; c.wg = 0; c.wG = 1; c.wpool = nullptr; c.wtimeout = 0;
-    c.crop_y = (g_cdouble_p)(P.crop_y + cd.crop_off); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.crop_off); c.ell_meta = (g_cu32_p)(P.ell_meta + cd.crop_off);
-    c.ell_i4 = (g_cu16x4_p)(P.ell_idx + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(P.ell_w + cd.ell_off);
-#pragma unroll
-    for (int j = 0; j < SDSM_ELL_GROUPS_REG; j++) c.gcount[j] = M > 0 ? st.gcount[j] : 0;
+    c.N = cd.N; c.NR = st.NR; c.hzmax = M > 0 ? st.hzmax : 0; c.env_size = efull;
+    c.p_lo = 0; c.p_hi = st.NR; c.wg = 0; c.wG = 1; c.wpool = nullptr; c.wtimeout = 0;
+    c.crop_y2 = (g_cf64x2_p)(P.crop_y + cd.run_off * SDSM_RUN); c.crop_rc = (g_cu32_p)(P.crop_rc + cd.run_off); c.meta = (g_cu32_p)(P.run_meta + cd.run_off);
+    c.aux = (g_cu32_p)(P.run_aux + cd.run_off);
+    c.ell_im = (g_cu32_p)(P.ell_im + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(reinterpret_cast<const f32x4 *>(P.ell_w) + cd.ell_off);
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N; c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * M;
-    fx_exponents(st.yexp, cd.N, &c.fxh_hi, &c.fxg_hi);
+    c.yexp = st.yexp;
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
     c.inv_hr = 1.0 / (half_r < 1 ? 1 : half_r); c.inv_hc = 1.0 / (half_c < 1 ? 1 : half_c);
@@ -1652,7 +1763,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const double psi_value = eval_value<L>(c, L::X, M);
-    const double psi_full = M == 0 ? eval_full_ell<L>(c PROF_ARG) : eval_full_sparse<L>(c, M, 0.0 PROF_ARG);
+    const double psi_full = eval_full<L>(c, M, 0.0, psi_value PROF_ARG);
     __syncthreads();
     if (tid == 0) {
         double Rm[6][6];                                   // theta_local = Rm theta_global (reparam is linear in theta)

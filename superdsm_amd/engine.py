@@ -245,47 +245,62 @@ class Batch:
 
     def inspect(self):
         """Setup-phase outputs for parity tests: per candidate (N, M, status, pixel coordinates, grid points,
-        CSR-like G~ rows).  Reads the workspace back to the host."""
+        CSR-like G~ rows), reconstructed PER PIXEL from the run-packed crop (a run = the region pixels of one image row inside one
+        aligned 4-column cell; an entry of a run holds the weights of its four pixels for one grid point).  Reads the workspace back
+        to the host."""
         lay = np.zeros(16, np.int64)
         _capi.check(_capi.lib().sdsm_plan_layout(self.plan, lay.ctypes.data_as(C.c_void_p)), 'sdsm_plan_layout')
         ws = self.ws.cpu().numpy()
-        zcap, npix, nell, ssz = int(lay[9]), int(lay[12]), int(lay[13]), int(lay[14])
+        zcap, csz, nell, ssz, nruns = int(lay[9]), int(lay[11]), int(lay[13]), int(lay[14]), int(lay[15])
+        cand = ws[lay[0]:lay[0] + csz * self.n].reshape(self.n, csz)
+        i64 = lambda c, o: int(cand[c, o:o + 8].view(np.int64)[0])
+        i32 = lambda c, o: int(cand[c, o:o + 4].view(np.int32)[0])
         state = ws[lay[1]:lay[1] + ssz * self.n].view(np.int32).reshape(self.n, ssz // 4)   # CandState
-        crop_y = ws[lay[2]:lay[2] + 8 * npix].view(np.float64)
-        crop_rc = ws[lay[3]:lay[3] + 4 * npix].view(np.uint32)
-        ell_meta = ws[lay[5]:lay[5] + 4 * npix].view(np.uint32)
+        crop_y = ws[lay[2]:lay[2] + 32 * nruns].view(np.float64).reshape(-1, 4)
+        crop_rc = ws[lay[3]:lay[3] + 4 * nruns].view(np.uint32)
+        run_meta = ws[lay[5]:lay[5] + 4 * nruns].view(np.uint32)
         xi_off = self.xi_offsets()
         grid = ws[lay[6]:].view(np.uint32)
-        ell_idx = ws[lay[7]:lay[7] + 2 * nell].view(np.uint16)
-        ell_w = ws[lay[8]:lay[8] + 4 * nell].view(np.float32)
+        ell_im = ws[lay[7]:lay[7] + 4 * nell].view(np.uint32)
+        ell_w = ws[lay[8]:lay[8] + 16 * nell].view(np.float32).reshape(-1, 4)
         out = []
-        po = 0
         for i in range(self.n):
             N = int(self.n_pixels[i])
             M, status, hc, wc, npos = (int(v) for v in state[i, :5])
-            rc = crop_rc[po:po + N]
+            NR = int(state[i, 18])
+            ro, eo = i64(i, 96), i64(i, 8)
             g = grid[xi_off[i]:xi_off[i] + M]
-            eo = po * zcap
-            nnz = (ell_meta[po:po + N] & 0xffff).astype(np.int64)
-            hnz = (ell_meta[po:po + N] >> 16).astype(np.int64)
-            # entry s of position p: element ((s // 4) * N + p) * 4 + s % 4  ->  [slot, position]
-            unpack = lambda a: a[eo:eo + N * zcap].reshape(zcap // 4, N, 4).transpose(0, 2, 1).reshape(zcap, N)
-            idx = unpack(ell_idx).astype(np.int64) if N else np.zeros((zcap, 0), np.int64)
-            w = unpack(ell_w) if N else np.zeros((zcap, 0), np.float32)
-            live = np.arange(zcap)[:, None] < nnz[None, :]       # slots past the row's end hold padding or nothing
-            idx, w = np.where(live, idx, 0), np.where(live, w, np.float32(0))
-            # the entries used by the solver's Hessian come first in a row; report rows by column index
-            key = np.where(np.arange(zcap)[:, None] < nnz[None, :], idx, 1 << 30)
-            srt = np.argsort(key, axis=0, kind='stable')
-            idx = np.take_along_axis(idx, srt, axis=0)
-            w = np.take_along_axis(w, srt, axis=0)
-            # the crop is stored by descending row length (scan order = a scatter of the raster order); report it in raster order
-            o = np.lexsort(((rc & 0xffff), (rc >> 16)))
-            out.append(dict(N=N, M=M, status=status, hc=hc, wc=wc, npos=npos, zmax=int(state[i, 5]), env_size=int(state[i, 15]), y=crop_y[po:po + N][o].copy(),
-                            r=(rc >> 16).astype(np.int64)[o], c=(rc & 0xffff).astype(np.int64)[o],
-                            grid_r=(g >> 16).astype(np.int64), grid_c=(g & 0xffff).astype(np.int64), nnz=nnz[o], hnz=hnz[o],
-                            nnz_stored_order=nnz.copy(), hnz_stored_order=hnz.copy(), idx=idx[:, o].copy(), w=w[:, o].copy()))
-            po += N
+            have_runs = status == 0 and NR > 0
+            meta = run_meta[ro:ro + NR] if have_runs else np.zeros(0, np.uint32)
+            rnnz, rhz, pm = (meta & 0xfff).astype(np.int64), ((meta >> 12) & 0xfff).astype(np.int64), (meta >> 24).astype(np.int64)
+            rc = crop_rc[ro:ro + len(meta)]
+            rows, cols, ys, nnzs, hnzs, idxs, wts = [], [], [], [], [], [], []
+            zc = max(zcap, 1)
+            for p in range(len(meta)):
+                k = int(rnnz[p]) if M > 0 else 0
+                im = ell_im[eo + np.arange(k) * NR + p] if k else np.zeros(0, np.uint32)
+                w4 = ell_w[eo + np.arange(k) * NR + p] if k else np.zeros((0, 4), np.float32)
+                for q in range(4):
+                    if not (pm[p] >> q) & 1:
+                        continue
+                    rows.append(int(rc[p] >> 16)); cols.append(int(rc[p] & 0xffff) + q); ys.append(crop_y[ro + p, q])
+                    sel = w4[:, q] != 0                                  # a grid point outside the pixel's window: weight 0
+                    ci, cw = (im[sel] & 0xffff).astype(np.int64), w4[sel, q]
+                    o2 = np.argsort(ci, kind='stable')                   # report rows by column index
+                    col = np.zeros(zc, np.int64); wt = np.zeros(zc, np.float32)
+                    col[:len(ci)] = ci[o2]; wt[:len(ci)] = cw[o2]
+                    idxs.append(col); wts.append(wt); nnzs.append(len(ci))
+                    hnzs.append(int((((im >> (16 + q)) & 1) != 0).sum()))
+            rows, cols = np.asarray(rows, np.int64), np.asarray(cols, np.int64)
+            o = np.lexsort((cols, rows))                                   # the crop is stored by runs in sorted scatter order; report it in raster order
+            take = lambda a, dt: (np.asarray(a, dt)[o] if len(a) else np.zeros(0, dt))
+            idx = np.stack(idxs, axis=1)[:, o] if idxs else np.zeros((zc, 0), np.int64)
+            w = np.stack(wts, axis=1)[:, o] if wts else np.zeros((zc, 0), np.float32)
+            out.append(dict(N=N, M=M, status=status, hc=hc, wc=wc, npos=npos, zmax=int(state[i, 5]), env_size=int(state[i, 15]), NR=NR,
+                            y=take(ys, np.float64), r=rows[o] if len(rows) else rows, c=cols[o] if len(cols) else cols,
+                            grid_r=(g >> 16).astype(np.int64), grid_c=(g & 0xffff).astype(np.int64), nnz=take(nnzs, np.int64), hnz=take(hnzs, np.int64),
+                            run_nnz=rnnz.copy(), run_hnz=rhz.copy(), run_pixels=np.array([bin(int(v)).count('1') for v in pm], np.int64),
+                            idx=idx.copy(), w=w.copy()))
         return out
 
     def fragments(self, records, select=None, masks=None):

@@ -86,7 +86,7 @@ def test_setup_matches_oracle_exactly(gpu, tag):
         np.testing.assert_array_equal(s['grid_c'], sm.grid_c)
         nnz = np.diff(sm.indptr)
         np.testing.assert_array_equal(s['nnz'], nnz)
-        for i in range(0, s['N'], 7):                   # every 7th row, all entries: indices and float32-exact weights
+        for i in range(s['N']):                         # every row, all entries: indices and float32-exact weights
             lo, hi = sm.indptr[i], sm.indptr[i + 1]
             np.testing.assert_array_equal(s['idx'][:nnz[i], i], sm.indices[lo:hi])
             np.testing.assert_array_equal(s['w'][:nnz[i], i].astype(np.float64), sm.data[lo:hi])
@@ -210,14 +210,12 @@ def test_full_size_properties_bbbc039_like(gpu):
     res['batch'].launch()
     gpu.cuda.synchronize()
     recs2 = res['batch'].records()
-    # ... up to the order of the LDS float atomics that accumulate the xi part of gradient and Hessian: iterates (never
-    # the optimum) move in the last bits between launches
-    np.testing.assert_allclose(recs2['energy'], recs['energy'], rtol=1e-6, atol=1e-9)
-    np.testing.assert_array_equal(recs2['status'], recs['status'])
-    # permutation invariance: candidates are independent
+    # ... bit for bit: every sum over the pixels is an integer (fixed-point) sum or a sum in a fixed order
+    assert recs2.tobytes() == recs.tobytes()
+    # permutation invariance: candidates are independent, and a candidate's numbers do not depend on its place in the plan
     perm = np.random.default_rng(0).permutation(len(fps))
     res3 = testing.solve_scene_gpu(scene, footprints=[fps[i] for i in perm])
-    np.testing.assert_allclose(res3['records']['energy'], recs['energy'][perm], rtol=1e-6, atol=1e-9)
+    assert res3['records'].tobytes() == recs[perm].tobytes()
     # fragments stay inside the region bounding box and contain only region pixels
     img, batch = res['image'], res['batch']
     for k in range(0, len(fps), 17):
@@ -327,8 +325,7 @@ def test_large_scale_workloads_match_oracle(gpu, workload):
     # every size class incl. the global-memory one (6 + M > 172) must be exercised by these scenes
     n = recs['n_deform'] + 6
     assert (n > 172).any() and ((n > 84) & (n <= 172)).any() and (n <= 40).any()
-    order = np.argsort(recs['n_pixels'])
-    sample = sorted(set([int(order[-1]), int(order[-2]), int(order[len(order) // 2]), int(order[0]), 0, len(fps) // 3]))
+    sample = list(range(len(fps)))                          # every candidate (90 / 234: seconds for the oracle on the box's cores)
     orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], [fps[i] for i in sample], scene['dsm_cfg'], nthreads=0)
     for j, k in enumerate(sample):
         assert (recs['n_pixels'][k], recs['n_deform'][k]) == (orecs['N'][j], orecs['M'][j])
@@ -779,6 +776,12 @@ def test_synthetic4096_matches_oracle(gpu):
         tol = 1e-6 * orecs['N'][j] / 1000 + 1e-5 * abs(orecs['energy'][j])
         if orecs['energy'][j] < 1e-3:                      # separable region: psi has no finite minimiser, inf psi = 0; the value is the stopping rule's
             assert recs['energy'][k] <= orecs['energy'][j] + tol, (k, recs['energy'][k], orecs['energy'][j])
+        elif np.abs(orecs['theta'][j]).max() > 1e9 and orecs['energy'][j] < 1e-4 * orecs['N'][j] * np.log(2):
+            # a region that is separable but for a pixel or two: the model runs off (theta ~ 1e14 after 80 iterations here), the Hessian
+            # is singular to working precision and WHERE the iteration stops is decided by the rounding of its pivots; both values are
+            # 1e-4 of the energy of the empty model (N ln 2) and mean "no energy" to the set cover (beta >= 100)
+            assert recs['energy'][k] < 1e-4 * orecs['N'][j] * np.log(2), (k, recs['energy'][k], orecs['energy'][j])
+            continue
         else:
             assert abs(recs['energy'][k] - orecs['energy'][j]) <= tol, (k, recs['energy'][k], orecs['energy'][j])
         assert testing.dice(res['fragments'][k][0], res['fragments'][k][1], orecs['fg_offset'][j], ofrags[j], scene['y'].shape) >= 0.999, k
@@ -905,7 +908,8 @@ def test_failed_dsm_solve_falls_back_and_failed_elliptical_solve_is_an_error(gpu
 
 def test_more_than_1018_deformation_parameters_is_reported_as_unsupported(gpu):
     """6 + M > 1024 exceeds the solver's limit (DESIGN.md "Limits"): status UNSUPPORTED with the elliptical result -- for an
-    ordinary region and for one that is solved by a workgroup group -- and an exception through compute_objects."""
+    ordinary region and for one that is solved by a workgroup group -- and through compute_objects a usable object: the elliptical
+    solution as a fallback with a warning, never an abort of the batch (objects.py:399-410: failure => fallback)."""
     from oracle import oracle
     from superdsm_amd import _capi, engine, image, objects
     rng = np.random.default_rng(8)
@@ -934,10 +938,17 @@ def test_more_than_1018_deformation_parameters_is_reported_as_unsupported(gpu):
         assert abs(recs['energy'][k] - erecs['energy'][k]) <= 1e-6 * abs(erecs['energy'][k])
         assert abs(recs['energy'][k] - recs['energy_ell'][k]) <= 1e-9 * abs(recs['energy'][k])
     yi = image.Image.create_from_array(y, normalize=False)
-    o = objects.Object()
-    o.footprint = {1}
-    with pytest.raises(_capi.SdsmError):
-        objects.compute_objects([o], yi, atoms, cfg, None, out='muted')
+    objs = []
+    for fp in fps:
+        o = objects.Object()
+        o.footprint = set(fp)
+        objs.append(o)
+    with pytest.warns(RuntimeWarning, match='elliptical solution is returned'):
+        objects.compute_objects(objs, yi, atoms, cfg, None, out='muted')
+    assert [o.is_optimal for o in objs] == [False, True, False]
+    for k in (0, 2):
+        assert abs(objs[k].energy - erecs['energy'][k]) <= 1e-6 * abs(erecs['energy'][k])
+        assert objs[k].fg_fragment.any() and objs[k].fg_fragment.shape == tuple(int(v) for v in (recs['fg_h'][k], recs['fg_w'][k]))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -988,9 +999,10 @@ def test_multi_image_plan_equals_single_image_plans(gpu):
         for i in range(len(s['footprints'])):
             j = pos[k0 + i]
             assert (mrec['n_pixels'][j], mrec['n_deform'][j], mrec['status'][j]) == (srec['n_pixels'][i], srec['n_deform'][i], srec['status'][i])
-            assert abs(mrec['energy'][j] - srec['energy'][i]) <= 1e-6 * abs(srec['energy'][i]) + 1e-9
-            assert mrec['on_boundary'][j] == srec['on_boundary'][i]
-            assert testing.dice(mfr[j][0], mfr[j][1], sfr[i][0], sfr[i][1], s['y'].shape) >= 0.999
+            # byte for byte: a candidate's record and mask do not depend on the plan it is in (other images, other candidates,
+            # another scheduling mode -- the single-image plan runs 192- and the other 256-thread workgroups for the same regions)
+            assert mrec[j].tobytes() == srec[i].tobytes(), (k, i)
+            assert tuple(mfr[j][0]) == tuple(sfr[i][0]) and np.array_equal(mfr[j][1], sfr[i][1])
         k0 += len(s['footprints'])
 
 
@@ -1014,7 +1026,12 @@ def test_image_set_in_lock_step_equals_image_by_image(gpu):
         stage(alone, cfg, out='muted')
         cov = lambda dd: sorted(sorted(int(a) for a in o.footprint) for o in dd['cover'].solution)
         assert cov(d) == cov(alone)
-        assert abs(d['cover'].costs - alone['cover'].costs) <= 1e-6 * abs(alone['cover'].costs)
+        assert d['cover'].costs == alone['cover'].costs
+        # `process` and `process_many`: identical energies, bit for bit (a candidate's numbers do not depend on its batch: the threshold
+        # comparisons of globalenergymin.py:361 cannot flip between the two)
+        ea = {tuple(sorted(int(a) for a in o.footprint)): float(o.energy).hex() for o in alone['objects']}
+        ed = {tuple(sorted(int(a) for a in o.footprint)): float(o.energy).hex() for o in d['objects']}
+        assert ea == ed
         for k in d['performance'].attributes:
             assert getattr(d['performance'], k) == getattr(alone['performance'], k)
     # the first image against the oracle-driven stage
@@ -1324,10 +1341,12 @@ def test_regression_metric_gpu_pipeline_vs_cpu_oracle_pipeline(gpu):
 
 
 def test_launches_reproduce_their_results_bit_for_bit(gpu):
-    """The sums of a solve do not depend on the order in which lanes, wavefronts or workgroups add to them: per-lane register sums
-    are reduced by fixed shuffle trees, the scattered Hessian / gradient contributions are integer (fixed-point) atomics, the
-    members of a workgroup group are added in member order.  So a launch repeated -- alone, or with the candidates of a second
-    copy of the image interleaved, which changes what runs beside what -- returns the same 128-byte records and the same masks."""
+    """The sums of a solve do not depend on the order in which lanes, wavefronts or workgroups add to them: everything that is summed
+    over the pixels is an integer (fixed-point) sum -- gradient, Hessian, coordinate moments --, except psi, whose chunk totals (64 runs,
+    a wavefront butterfly) are added in a fixed order.  So a launch repeated -- alone, with the candidates of a second copy of the
+    image interleaved (which changes what runs beside what and how many workgroups share the very large regions), or in another
+    scheduling mode (another workgroup size, other size classes, no workgroup groups at all) -- returns the same 128-byte records and
+    the same masks."""
     from superdsm_amd import engine, testing
     for workload, stride in (('bbbc039_like', 1), ('gowt1_like', 1)):
         scene = testing.make_scene(workload, max_size=3 if workload == 'bbbc039_like' else 2)
@@ -1343,6 +1362,12 @@ def test_launches_reproduce_their_results_bit_for_bit(gpu):
         assert (runs[0][0]['status'] != 1).any()
         assert runs[0][0].tobytes() == runs[1][0].tobytes()
         assert (runs[0][1] == runs[1][1]).all()
+        for mode in (1, 2):                                              # latency scheduling; no workgroup groups
+            other = engine.Batch(img, fps, cfg, mode=mode)
+            other.launch()
+            orec, omask = other.download()
+            assert orec.tobytes() == runs[0][0].tobytes(), (workload, mode, np.flatnonzero(orec['energy'] != runs[0][0]['energy'])[:5])
+            assert (omask == runs[0][1]).all()
         img2 = engine.DeviceImage(scene['y'].copy(), None, scene['atoms'].copy(), cfg['background_margin'])
         both = engine.Batch([img, img2], [fp for fp in fps for _ in range(2)], cfg, image_of=[k for _ in fps for k in range(2)])
         both.launch()
@@ -1351,14 +1376,10 @@ def test_launches_reproduce_their_results_bit_for_bit(gpu):
         fr2 = both.fragments(rec2, masks=mask2)
         for i in range(len(fps)):
             assert rec2[2 * i].tobytes() == rec2[2 * i + 1].tobytes(), (workload, i)          # the two copies inside one launch
-            if runs[0][0]['n_pixels'][i] <= 12288:
-                assert rec2[2 * i].tobytes() == runs[0][0][i].tobytes(), (workload, i)
-            else:
-                # a region of more than 12 288 pixels is solved by a workgroup group while the launch has compute units to spare (the
-                # largest regions first, 256 members per launch): the doubled plan may give it fewer members or none -- another summation
-                # order of the slices, the same result to rounding (limits)
-                np.testing.assert_allclose(rec2[2 * i]['energy'], runs[0][0][i]['energy'], rtol=1e-9)
-                assert rec2[2 * i]['status'] == runs[0][0][i]['status']
+            # also for the regions of more than 12 288 pixels, which are solved by a workgroup group while the launch has compute units
+            # to spare (the doubled plan may give them fewer members or none): integer sums and the fixed order of the psi sums do not
+            # depend on how many workgroups share a candidate
+            assert rec2[2 * i].tobytes() == runs[0][0][i].tobytes(), (workload, i)
             for k in range(2):
                 assert tuple(fr2[2 * i + k][0]) == tuple(fr1[i][0]) and np.array_equal(fr2[2 * i + k][1], fr1[i][1])
 
