@@ -12,9 +12,15 @@ neither several streams nor an environment variable.
 `python bench.py --gpus N` with WORLD_SIZE unset starts the N ranks itself (fresh child processes, created before anything
 touches the GPU); under torchrun it is one rank.  Prints ONE JSON line on rank 0.
 
+The 8 images of a step are 8 DIFFERENT BBBC039-like images (ellipses at the centres / areas of eight of the reference's per-image
+regression tables, 68 .. 170 objects).  The default run also measures the other BASELINE.json configs (`extras.configs`: GOWT1-like
+frame, NIH3T3-like image set through the stage, synthetic 4096^2), each with its launch time, solves/s and roofline fraction.
+
 Other workloads: --workload {gowt1_like,nih3t3_like,synthetic4096,synthetic256} (one image per step);
 --mode image_set: BASELINE.json configs[3] -- a set of NIH3T3-like images dealt to the ranks, every rank runs the
-global-energy-minimisation stage on its images in lock step (process_many), one gather of the results at the end.
+global-energy-minimisation stage on its images in lock step (process_many), one gather of the results at the end;
+--mode sharded: BASELINE.json configs[4] as specified -- the candidates of ONE batch (default: the synthetic 4096^2 image) dealt to the
+ranks by cost, every rank solves its share, ONE all-gather of records + masks per step (strong scaling).
 """
 import argparse
 import gc
@@ -38,7 +44,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='bbbc039_like')
-    ap.add_argument('--mode', default='solves', choices=['solves', 'image_set'])
+    ap.add_argument('--mode', default='solves', choices=['solves', 'image_set', 'sharded'])
+    ap.add_argument('--min-gpu-seconds', type=float, default=2.0, help='the timed regions are repeated until they add up to this much (so that an outside sampler of GPU activity sees the run)')
+    ap.add_argument('--no-configs', action='store_true', help='skip the other BASELINE.json configs in extras')
     ap.add_argument('--images', type=int, default=None, help='images per plan = per step (default: 8 for bbbc039_like / synthetic256, else 1)')
     ap.add_argument('--max-size', type=int, default=3, help='candidates = connected atom subsets up to this size + universes')
     ap.add_argument('--repeats', type=int, default=5, help='the timed region of --steps steps is repeated; the median is reported')
@@ -81,28 +89,35 @@ def spawn_ranks(args):
 # ---------------------------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle = CPU restatement of the reference path, kind "port")
 # ---------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(scene, n_images, budget_s):
-    """The oracle on the same work as one GPU step -- the candidates of all `n_images` images in ONE OpenMP loop, one candidate
+def cpu_baseline(scenes, budget_s):
+    """The oracle on the same work as one GPU step -- the candidates of all images, every image's in ONE OpenMP loop, one candidate
     per worker (Ray: one task per core, objects.py:280) -- in two variants: a worker per core, and cores / 2 workers with 2 threads
     each (MKL_NUM_THREADS: 2 of the reference's task specs, examples/BBBC039/task.json:4).  Each variant is a bounded sample."""
     from oracle import oracle
-    fps = scene['footprints'] * n_images
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    uniq = list({id(sc): sc for sc in scenes}.values())
+    mult = len(scenes) // len(uniq)
+    ncand = sum(len(sc['footprints']) for sc in scenes)
+
+    def one_pass(workers, inner):
+        for sc in uniq:
+            oracle.compute_objects(sc['y'], None, sc['atoms'], sc['footprints'] * mult, sc['dsm_cfg'], nthreads=workers, inner_threads=inner)
+
     out = {}
     for key, workers, inner in (('per_core', cores, 1), ('half_cores_x2', max(1, cores // 2), 2)):
         t0 = time.time()
-        oracle.compute_objects(scene['y'], None, scene['atoms'], fps, scene['dsm_cfg'], nthreads=workers, inner_threads=inner)
+        one_pass(workers, inner)
         t_once = time.time() - t0
         reps = int(max(1, min(50, round(budget_s / max(t_once, 1e-3)))))
         t0 = time.time()
         for _ in range(reps):
-            oracle.compute_objects(scene['y'], None, scene['atoms'], fps, scene['dsm_cfg'], nthreads=workers, inner_threads=inner)
+            one_pass(workers, inner)
         dt = time.time() - t0
-        out[key] = dict(value=reps * len(fps) / dt, workers=workers, threads_per_worker=inner,
-                        sample=f'{len(fps)} candidates ({n_images} images x {len(scene["footprints"])}) x {reps} passes in one OpenMP loop, {dt:.1f} s wall')
+        out[key] = dict(value=reps * ncand / dt, workers=workers, threads_per_worker=inner,
+                        sample=f'{ncand} candidates (the {len(scenes)} images of one GPU step, one OpenMP loop per image) x {reps} passes, {dt:.1f} s wall')
     best = max(out.values(), key=lambda v: v['value'])
     return dict(value=best['value'], unit='candidate solves/s', cores=cores, kind='port', sample=best['sample'],
                 variants=out, note='CPU restatement of the reference path (oracle/), not the reference itself and not the target')
@@ -163,8 +178,7 @@ def main():
     args = parse()
     if args.gpus * args.ranks_per_gpu > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
-    if args.inflight > 4:
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # ROCm maps streams onto 4 hardware queues by default
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '16' if args.inflight > 4 else '8')      # ROCm maps streams onto 4 hardware queues by default; a launch uses the caller's stream + 3
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -177,34 +191,56 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend, rank=rank, world_size=world)
+    # GPUs this run really uses: ranks are placed on device (local_rank // rpg) % ndev -- fewer devices than ranks / rpg means sharing
+    # (a dry run on a box without devices reports the requested count next to devices_visible = 0)
+    n_gpus_used = max(1, min(max(1, world // rpg), ndev)) if ndev > 0 else max(1, world // rpg)
     if args.dry_run:
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        shard_sizes = None
         if world > 1:
             dist.barrier()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if args.mode == 'sharded':                                # the dealing of one batch and its one all-gather, on fake costs / payloads
+            from superdsm_amd import dist as sdist
+            costs = np.random.default_rng(5).integers(200, 20000, 1000)
+            shards = sdist.shard_indices(costs, world)
+            pad = max(128 * len(sh) for sh in shards)
+            send = torch.full((pad,), rank, dtype=torch.uint8)
+            recv = torch.empty(world * pad, dtype=torch.uint8)
+            if world > 1:
+                dist.all_gather(list(recv.chunk(world)), send)
+            else:
+                recv.copy_(send)
+            assert all(int(recv[r * pad]) == r for r in range(world))
+            shard_sizes = [len(sh) for sh in shards]
         if rank == 0:
-            print(json.dumps({'metric': 'candidate DSM solves/sec', 'value': 0.0, 'unit': 'candidate solves/s', 'n_gpus': max(1, world // rpg), 'steps': args.steps,
-                              'warmup': args.warmup, 'ms_per_step': float(t.item()), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                              'dtype': 'f64', 'data': 'none (dry run of the rank plumbing)', 'config': {'workload': 'dry-run', 'backend': backend}}))
+            print(json.dumps({'metric': 'candidate DSM solves/sec', 'value': 0.0, 'unit': 'candidate solves/s', 'n_gpus': n_gpus_used, 'steps': args.steps,
+                              'warmup': args.warmup, 'ms_per_step': float(t.item()), 'higher_is_better': True, 'scaling': 'strong' if args.mode == 'sharded' else 'weak', 'vs_baseline': None,
+                              'dtype': 'f64', 'data': 'none (dry run of the rank plumbing)',
+                              'config': {'workload': 'dry-run', 'backend': backend, 'mode': args.mode, 'ranks': world, 'devices_visible': ndev, 'shard_sizes': shard_sizes}}))
         if world > 1:
             dist.destroy_process_group()
         return
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the DSM solve path has no CPU fallback)'
     torch.cuda.set_device((local_rank // rpg) % ndev)
     if args.mode == 'image_set':
-        return image_set_mode(args, world, rank, backend)
+        return image_set_mode(args, world, rank, backend, n_gpus_used)
+    if args.mode == 'sharded':
+        return sharded_mode(args, world, rank, backend, n_gpus_used)
 
     from superdsm_amd import _capi, engine, testing
     from superdsm_amd import dist as sdist
 
-    scene = testing.make_scene(args.workload, max_size=args.max_size)
-    fps1 = scene['footprints']
     n_images = args.images if args.images else (8 if args.workload in ('bbbc039_like', 'synthetic256') else 1)
+    # `n_images` images per step; BBBC039-like: DIFFERENT images (eight of the reference's per-image object tables place the nuclei)
+    scenes = [testing.make_scene(args.workload, max_size=args.max_size, layout_index=k % 8 if args.workload == 'bbbc039_like' else 0) for k in range(n_images)] \
+        if args.workload == 'bbbc039_like' else [testing.make_scene(args.workload, max_size=args.max_size)] * n_images
+    scene = scenes[0]
+    fps1 = scene['footprints']
     margin = scene['dsm_cfg']['background_margin']
-    # `n_images` images per step, each with its own copy of y / atoms in HBM (synthetic: the same content)
-    imgs = [engine.DeviceImage(scene['y'], None, scene['atoms'], margin) for _ in range(n_images)]
-    fps = fps1 * n_images
-    image_of = np.repeat(np.arange(n_images, dtype=np.int32), len(fps1))
+    imgs = [engine.DeviceImage(sc['y'], None, sc['atoms'], margin) for sc in scenes]
+    fps = [fp for sc in scenes for fp in sc['footprints']]
+    image_of = np.concatenate([np.full(len(sc['footprints']), k, np.int32) for k, sc in enumerate(scenes)])
     nfl = max(1, min(args.inflight, args.steps))
     batches = [engine.Batch(imgs, fps, scene['dsm_cfg'], image_of=image_of) for _ in range(nfl)]
     streams = [torch.cuda.Stream() for _ in range(nfl)]
@@ -230,7 +266,8 @@ def main():
         step(i)
     torch.cuda.synchronize()
     region_ms = []
-    for _ in range(max(1, args.repeats)):      # the timed region: EXACTLY --steps steps, barrier + synchronize on both sides
+    n_regions = max(1, args.repeats)
+    while len(region_ms) < n_regions:          # the timed region: EXACTLY --steps steps, barrier + synchronize on both sides
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -246,6 +283,8 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         region_ms.append(dt * 1e3)
+        if len(region_ms) == n_regions and sum(region_ms) < args.min_gpu_seconds * 1e3 and n_regions < 400:
+            n_regions = min(400, max(n_regions + 1, int(np.ceil(args.min_gpu_seconds * 1e3 / np.median(region_ms)))))   # (the same count on every rank: the times are all-reduced)
     dt = float(np.median(region_ms)) * 1e-3
 
     # kernel-level timing with HIP events on the launch stream (one launch at a time)
@@ -267,17 +306,20 @@ def main():
     z = 11.0
     flops = float((evals * recs['n_pixels'] * (4 * (6 + z) + 20)).sum() + (recs['evals_full'].astype(np.int64) * recs['n_pixels'] * (6 + z) ** 2).sum())
     out = {
-        'metric': 'candidate DSM solves/sec', 'value': value, 'unit': 'candidate solves/s', 'n_gpus': max(1, world // rpg), 'steps': args.steps,
+        'metric': 'candidate DSM solves/sec', 'value': value, 'unit': 'candidate solves/s', 'n_gpus': n_gpus_used, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'{args.workload} {scene["y"].shape[0]}x{scene["y"].shape[1]} (BASELINE.json configs[1] stand-in: ellipses at the centres/areas of a '
-                               f'reference BBBC039 regression CSV), {n_images} images per step in ONE launch, all candidates of every image: connected atom '
+        'config': {'workload': f'{args.workload} {scene["y"].shape[0]}x{scene["y"].shape[1]} (BASELINE.json configs[1] stand-in: ellipses at the centres/areas of '
+                               f'{len(set(id(sc) for sc in scenes))} different reference BBBC039 regression tables), {n_images} images per step in ONE launch, all candidates of every image: connected atom '
                                f'subsets of size <= {args.max_size} + cluster universes',
-                   'images_per_step': n_images, 'candidates_per_image': len(fps1), 'candidates_per_step_per_gpu': len(fps), 'atoms_per_image': int(scene['atoms'].max()),
+                   'images_per_step': n_images, 'candidates_per_image': [len(sc['footprints']) for sc in scenes], 'candidates_per_step_per_gpu': len(fps),
+                   'atoms_per_image': [int(sc['atoms'].max()) for sc in scenes], 'backend': backend if world > 1 else None,
+                   'ranks': world, 'ranks_per_gpu': rpg, 'devices_visible': ndev,
                    'median_N': int(np.median(recs['n_pixels'])), 'median_M': int(np.median(recs['n_deform'])),
                    'parallelism': f'{world} ranks ({rpg} per GPU), weak scaling: every rank solves its own images, one gather of records + masks per step (RCCL with one rank per GPU)'
                                   if world > 1 else 'single GPU',
-                   'steps_in_flight': nfl, 'timed_regions_ms': region_ms, 'value_is': 'median over the timed regions'},
+                   'steps_in_flight': nfl, 'timed_regions': len(region_ms), 'timed_regions_ms_min_median_max': [float(np.min(region_ms)), float(np.median(region_ms)), float(np.max(region_ms))],
+                   'timed_seconds_total': float(sum(region_ms) * 1e-3), 'value_is': 'median over the timed regions'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
                      'traffic': measured_traffic(args.workload, n_images),
                      'kernel': 'sdsm_k_solve (the size classes of one launch run concurrently; class 1 <128, 2560, 256 threads> does the work here)',
@@ -285,13 +327,16 @@ def main():
                      'achieved_in_timed_region': alg_bytes / (dt / args.steps) / 1e9,
                      'fp64_vector_tflops': flops / (kern_ms * 1e-3) / 1e12, 'fp64_vector_frac_of_78.6': flops / (kern_ms * 1e-3) / 1e12 / 78.6,
                      'pixel_evaluations_per_launch': int((evals * recs['n_pixels']).sum()),
-                     'pixel_evaluations_per_image': int((evals * recs['n_pixels']).sum() // n_images)},
+                     'pixel_evaluations_per_image': int((evals * recs['n_pixels']).sum() // n_images),
+                     'algorithmic_bytes_definition': 'SURVEY.md 8(d): sum over candidates of E_c (12 N_c + 8 (6 + M_c)) + 12 N_c + ceil(bbox_c / 8) + 128, E_c = passes over the pixels actually made'},
         'status_counts': {str(k): int(v) for k, v in zip(*np.unique(recs['status'], return_counts=True))},
     }
     if rank == 0 and world == 1 and not args.no_extras:
         out['extras'] = extras(args, scene, imgs[0], n_images)
+        if not args.no_configs and args.workload == 'bbbc039_like':
+            out['extras']['configs'] = other_configs(args)
     if rank == 0 and not args.no_cpu and world == 1:
-        out['cpu_baseline'] = cpu_baseline(scene, n_images, args.cpu_seconds)
+        out['cpu_baseline'] = cpu_baseline(scenes, args.cpu_seconds)
         if 'extras' in out and args.workload in ('bbbc039_like', 'synthetic256'):
             ms, ncomp = cpu_stage_wall(scene, 150.0, 'isbi24')
             out['extras']['stage_wall_ms_per_image_cpu_oracle'] = ms
@@ -394,7 +439,122 @@ def extras(args, scene, img, n_images):
     return ex
 
 
-def image_set_mode(args, world, rank, backend):
+def launch_figures(scene, n_timed=5):
+    """One engine launch over all candidates of one image (throughput scheduling, as the headline step): wall clock per launch, HIP-event
+    time of the solve kernels, solves/s and the roofline fraction by SURVEY.md 8(d)'s byte count."""
+    import torch
+    from superdsm_amd import _capi, engine
+    L = _capi.lib()
+    img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
+    batch = engine.Batch(img, scene['footprints'], scene['dsm_cfg'])
+    for _ in range(2):
+        batch.launch()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n_timed):
+        t1 = time.perf_counter()
+        batch.launch()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t1) * 1e3)
+    L.sdsm_enable_kernel_timing(1)
+    km, sm = [], []
+    for _ in range(3):
+        batch.launch()
+        km.append(L.sdsm_last_solve_kernel_ms())
+        sm.append(L.sdsm_last_setup_kernel_ms())
+    L.sdsm_enable_kernel_timing(0)
+    recs = batch.records()
+    alg = engine.algorithmic_bytes(recs, batch.mask_info)
+    ms = float(np.median(ts))
+    kern = float(np.mean(km))
+    return dict(image=f'{scene["y"].shape[0]}x{scene["y"].shape[1]}', candidates=len(scene['footprints']), ms_per_launch=ms, solve_kernels_ms=kern, setup_kernel_ms=float(np.mean(sm)),
+                candidate_solves_per_s=len(scene['footprints']) / (ms * 1e-3), median_N=int(np.median(recs['n_pixels'])), max_N=int(recs['n_pixels'].max()),
+                median_M=int(np.median(recs['n_deform'])), max_M=int(recs['n_deform'].max()),
+                roofline={'bound': 'hbm', 'achieved': alg / (kern * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / (kern * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': alg},
+                status_counts={str(k): int(v) for k, v in zip(*np.unique(recs['status'], return_counts=True))})
+
+
+def other_configs(args):
+    """The BASELINE.json configs beside the headline one, each measured in this same run."""
+    import torch
+    from superdsm_amd import config, globalenergymin, testing
+    out = {}
+    sc = testing.make_scene('gowt1_like', max_size=3)
+    out['gowt1_like'] = dict(launch_figures(sc), stands_for='BASELINE.json configs[2]: GOWT1-1 frame (sparse nuclei, large regions), one launch = all candidates of the frame')
+    sc = testing.make_scene('nih3t3_like', max_size=2)
+    fig = launch_figures(testing.make_scene('nih3t3_like', max_size=3))
+    stage = globalenergymin.GlobalEnergyMinimization()
+    cfg = config.Config({'global-energy-minimization': {'beta': 1200.0, 'pruning': 'isbi24'}})
+    mk = lambda i: dict(y=np.ascontiguousarray(sc['y'] * (1 - 0.003 * i)), y_mask=np.ones(sc['y'].shape, bool), atoms=sc['atoms'], adjacencies=sc['adjacencies'], dsm_cfg=sc['dsm_cfg'])
+    stage.process_many([mk(0)], cfg, out='muted')
+    ts, ncand = [], 0
+    for _ in range(3):
+        ds = [mk(i) for i in range(3)]
+        gc.collect()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        stage.process_many(ds, cfg, out='muted')
+        ts.append((time.perf_counter() - t1) * 1e3 / 3)
+        ncand = sum(int(d['performance'].overall_computed_object_count) for d in ds)
+    out['nih3t3_like'] = dict(fig, stands_for='BASELINE.json configs[3] on ONE GPU: NIH3T3-like images; launch figures for all candidates of one image, and the whole '
+                                              'global-energy-minimisation stage on a set of 3 images in lock step (image sets over N GPUs: --mode image_set)',
+                              stage_wall_ms_per_image_set_of_3=float(np.median(ts)), stage_candidates_set_of_3=ncand)
+    sc = testing.make_scene('synthetic4096', max_size=3)
+    out['synthetic4096'] = dict(launch_figures(sc, n_timed=3), stands_for='BASELINE.json configs[4] on ONE GPU: synthetic 4096x4096, ~2000 dense overlapping nuclei, every candidate in one launch '
+                                                                           '(over N GPUs as ONE sharded batch: --mode sharded)')
+    return out
+
+
+def sharded_mode(args, world, rank, backend, n_gpus_used):
+    """BASELINE.json configs[4] as specified (strong scaling): the candidates of ONE batch dealt to the ranks by cost (dist.Sharder),
+    every rank solves its share on its GPU, ONE all-gather of records + bit-packed masks per step.  value = candidates of the batch / s."""
+    import torch
+    import torch.distributed as dist
+    from superdsm_amd import engine, testing
+    from superdsm_amd import dist as sdist
+    wl = args.workload if args.workload != 'bbbc039_like' or args.images_workload_explicit else 'synthetic4096'
+    scene = testing.make_scene(wl, max_size=args.max_size)
+    img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
+    if world == 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group(backend, rank=0, world_size=1)
+    sb = sdist.Sharder().prepare(img, scene['footprints'], scene['dsm_cfg'])
+    for _ in range(max(1, args.warmup)):
+        sb.step()
+    torch.cuda.synchronize()
+    region_ms = []
+    for _ in range(max(1, min(args.repeats, 3))):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sb.step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        region_ms.append(float(tmax.item()) * 1e3)
+    recs, _ = sb.results()
+    if rank == 0:
+        dt = float(np.median(region_ms)) * 1e-3
+        n = len(scene['footprints'])
+        alg = engine.algorithmic_bytes(recs, sb.mask_info)
+        print(json.dumps({
+            'metric': 'candidate DSM solves/sec', 'value': n * args.steps / dt, 'unit': 'candidate solves/s', 'n_gpus': n_gpus_used, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'{wl} {scene["y"].shape[0]}x{scene["y"].shape[1]}: ONE batch of {n} candidates dealt to {world} ranks by cost (snake order), '
+                                   f'one all-gather of records + masks per step ({backend})', 'candidates': n, 'ranks': world, 'ranks_per_gpu': max(1, args.ranks_per_gpu),
+                       'shard_sizes': [len(sh) for sh in sb.shards], 'payload_bytes_per_rank': int(sb.pad), 'backend': backend,
+                       'timed_regions_ms': region_ms},
+            'roofline': {'bound': 'hbm', 'achieved': alg / (dt / args.steps) / 1e9 / max(1, n_gpus_used), 'peak': 8000.0, 'unit': 'GB/s per GPU (whole step incl. setup kernel and the gather)',
+                         'frac': alg / (dt / args.steps) / 8e12 / max(1, n_gpus_used), 'traffic': None, 'algorithmic_bytes_per_step': alg},
+            'status_counts': {str(k): int(v) for k, v in zip(*np.unique(recs['status'], return_counts=True))}, 'cpu_baseline': None}))
+    dist.destroy_process_group()
+
+
+def image_set_mode(args, world, rank, backend, n_gpus_used):
     """BASELINE.json configs[3]: a set of NIH3T3-like images dealt to the ranks; every rank runs the stage on its images in lock step,
     ONE gather of the per-image results (cover footprints, energies) at the end.  value = candidate solves / s over the whole set."""
     import torch
@@ -435,12 +595,12 @@ def image_set_mode(args, world, rank, backend):
         flat = sorted(x for part in got for x in part)
         ncand = sum(x[3] for x in flat)
         print(json.dumps({
-            'metric': 'candidate DSM solves/sec', 'value': ncand / dt, 'unit': 'candidate solves/s', 'n_gpus': max(1, world // max(1, args.ranks_per_gpu)), 'steps': 1, 'warmup': 1,
+            'metric': 'candidate DSM solves/sec', 'value': ncand / dt, 'unit': 'candidate solves/s', 'n_gpus': n_gpus_used, 'steps': 1, 'warmup': 1,
             'ms_per_step': dt * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{wl} image set (BASELINE.json configs[3] stand-in): {n_images} images of {scene["y"].shape[0]}x{scene["y"].shape[1]}, '
                                    f'{n_images // world} per rank, global-energy-minimisation stage in lock step, one gather of the results at the end',
-                       'images': n_images, 'candidates_solved': ncand, 'ranks_per_gpu': max(1, args.ranks_per_gpu), 'wall_ms_per_image_and_rank': dt * 1e3 / (n_images // world),
-                       'wall_ms_per_image': dt * 1e3 / n_images * max(1, world // max(1, args.ranks_per_gpu)), 'objects_in_covers': sum(len(x[1]) for x in flat)},
+                       'images': n_images, 'candidates_solved': ncand, 'ranks': world, 'ranks_per_gpu': max(1, args.ranks_per_gpu), 'backend': backend if world > 1 else None, 'wall_ms_per_image_and_rank': dt * 1e3 / (n_images // world),
+                       'wall_ms_per_image': dt * 1e3 / n_images * n_gpus_used, 'objects_in_covers': sum(len(x[1]) for x in flat)},
             'roofline': None, 'cpu_baseline': None}))
     if world > 1:
         dist.destroy_process_group()

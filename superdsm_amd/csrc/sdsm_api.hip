@@ -17,7 +17,8 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
-extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w, int cls);
+extern "C" hipError_t sdsm_launch_setup(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w, int cls, const int32_t *order_small, int n_small, const int32_t *order_big, int n_big);
+extern "C" int sdsm_setup_fits_small(int h, int w, int mcap, int max_label, int k);
 extern "C" int sdsm_setup_class(int max_dim, int max_mcap, int max_label, int k);
 
 static thread_local std::string g_err;
@@ -126,6 +127,7 @@ struct sdsm_plan {
     std::vector<CandDesc> cand;
     std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those whose bound on M admits more than solve class 1, then more than class 2
     int n_order_c = 0, n_order_d = 0, n_order_w = 0;   // the last list: (candidate | member << 24) of the workgroup groups
+    int n_setup_small = 0, n_setup_big = 0, max_label = 1;   // setup in two launches (plans that mix small and large regions): lists behind the others
     int setup_class = 2;         // LDS limits of the setup kernel that hold this plan (sdsm_setup_class)
     int mode = 0;                // sdsm_plan_set_latency_mode: 0 throughput, 1 latency, 2 no workgroup groups
     int wide_pixels = INT_MAX;   // throughput mode by default
@@ -134,7 +136,7 @@ struct sdsm_plan {
     std::vector<int64_t> mask_off_bytes, xi_off;
     int64_t total_pixels = 0, total_runs = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0, n_wide = 0;
     size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_run_meta = 0,
-           off_run_q0 = 0, off_run_aux = 0, off_grid = 0, off_ell_im = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, off_ticket = 0, total = 0;
+           off_run_q0 = 0, off_run_aux = 0, off_grid = 0, off_ell_im = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, off_ticket = 0, off_cls_list = 0, total = 0;
     // The launch lists and CandDesc.wide_* live in the workspace (sdsm_batch_upload): a layout change after the upload
     // (sdsm_plan_set_latency_mode) would leave stale tables on the device, so launches check the generation they were uploaded at.
     uint64_t layout_gen = 0;
@@ -244,6 +246,21 @@ static void layout_plan(sdsm_plan *p)
         const int ci = p->order[k];
         for (int g = 0; g < p->cand[ci].wide_g; g++) { p->order.push_back(ci | (g << 24)); p->n_order_w++; }
     }
+    // Setup: a plan whose largest region needs the large tables of the setup kernel (1024 threads per candidate) but whose candidates are
+    // mostly small (an image set with a few big clusters) sets the small ones up with the 256-thread class in a launch of its own
+    p->n_setup_small = p->n_setup_big = 0;
+    if (p->setup_class != 0) {
+        std::vector<int32_t> small, big;
+        for (int k = 0; k < n; k++) {
+            const CandDesc &c = p->cand[p->order[k]];
+            (c.N <= SDSM_SETUP_SMALL_PIXELS && sdsm_setup_fits_small(c.h, c.w, c.Mcap, p->max_label, p->k) ? small : big).push_back(p->order[k]);
+        }
+        if (small.size() >= 256) {
+            p->n_setup_small = (int)small.size(); p->n_setup_big = (int)big.size();
+            p->order.insert(p->order.end(), small.begin(), small.end());
+            p->order.insert(p->order.end(), big.begin(), big.end());
+        }
+    }
     // workspace layout
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
@@ -270,7 +287,8 @@ static void layout_plan(sdsm_plan *p)
     p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1));      // n_hglob counts doubles
     p->off_wide = take(8 * (size_t)std::max<int64_t>(p->n_wide, 1));        // n_wide counts doubles
-    p->off_ticket = take(256);
+    p->off_ticket = take(256);                                                // [0] ticket of the workgroup groups; [16 ..] counters of the class work lists (zeroed before every launch)
+    p->off_cls_list = take(4 * (size_t)SDSM_NLISTS * std::max(n, 1));
     p->total = o;
 }
 extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, const int32_t *W, const int32_t *n_atoms, const int32_t *const *atom_stats,
@@ -349,6 +367,7 @@ extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, con
         for (const CandDesc &c : p->cand) { max_dim = std::max(max_dim, std::max(c.h, c.w)); max_mcap = std::max(max_mcap, c.Mcap); }
         for (int im = 0; im < n_images; im++) max_label = std::max(max_label, n_atoms[im]);
         p->setup_class = sdsm_setup_class(max_dim, max_mcap, max_label, p->k);
+        p->max_label = max_label;
     }
     layout_plan(p);
     return p;
@@ -441,7 +460,7 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
 {
     uint8_t *b = (uint8_t *)d_ws;
     BatchParams P{};
-    P.n = p->n; P.n_images = (int)p->images.size();
+    P.n = p->n; P.n_total = p->n; P.pad_n = 0; P.n_images = (int)p->images.size();
     for (size_t i = 0; i < p->images.size(); i++) { P.img[i].H = p->images[i].H; P.img[i].W = p->images[i].W; }   // device pointers: filled by the launch
     P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.zcap_run = p->zcap_run; P.zshift = p->zshift; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
     P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels;
@@ -458,6 +477,7 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
     P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
     P.hglob = (double *)(b + p->off_hglob); P.wide_pool = (double *)(b + p->off_wide);
     P.wide_ticket = (int32_t *)(b + p->off_ticket); P.wide_timeout = g_wide_timeout;
+    P.cls_count = (int32_t *)(b + p->off_ticket) + 16; P.cls_list = (int32_t *)(b + p->off_cls_list);
     P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
     return P;
 }
@@ -500,7 +520,12 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
     for (size_t i = 0; i < p->images.size(); i++) { P.img[i].y = d_y[i]; P.img[i].atoms = d_atoms[i]; P.img[i].valid = d_valid[i]; }
     hipError_t e;
     if (g_timing && (e = hipEventRecord(g_ev[0], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
-    if ((e = sdsm_launch_setup(P, s, P.order + p->n + p->n_order_c + p->n_order_d, p->n_order_w, p->setup_class)) != hipSuccess) return hipfail(e, "launch setup");
+    if ((e = hipMemsetAsync((uint8_t *)d_ws + p->off_ticket, 0, 256, s)) != hipSuccess) return hipfail(e, "hipMemsetAsync");   // ticket, work-list counters
+    {
+        const int32_t *lists = P.order + p->n + p->n_order_c + p->n_order_d;
+        if ((e = sdsm_launch_setup(P, s, lists, p->n_order_w, p->setup_class, lists + p->n_order_w, p->n_setup_small, lists + p->n_order_w + p->n_setup_small, p->n_setup_big)) != hipSuccess)
+            return hipfail(e, "launch setup");
+    }
     if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
     hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
     hipEvent_t *fj = nullptr;

@@ -26,10 +26,10 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_MAX_GRID 2048         // grid points kept in LDS during setup
 #define SDSM_K1_NMAX 128           // solve class 1: 6 + M <= 128 and envelope <= SDSM_K1_EMAX doubles (LDS ~ 30 KB)
 #define SDSM_K1_EMAX 2560
-#define SDSM_K1B_NMAX 256          // solve class 1b: 6 + M <= 256 and envelope <= 6144 doubles: 256 threads, LDS ~ 68 KB, TWO workgroups per compute unit
-#define SDSM_K1B_EMAX 6144         //   (between class 1 and class 2, whose 157 KB leave one workgroup per compute unit: regions of ~5-15 k pixels, M ~ 100-250)
-#define SDSM_K2B_NMAX 512          // solve class 2b: 6 + M <= 512 and envelope <= 15200 doubles: the LDS that class 2 spends on vectors of 1024 unknowns
-#define SDSM_K2B_EMAX 15200        //   holds a larger envelope instead (~ 160 KB): keeps most of what class 2 cannot hold out of the global-memory class
+#define SDSM_K1B_NMAX 256          // solve class 1b: 6 + M <= 256 and envelope <= 7168 doubles: 256 threads, LDS ~ 79 KB, TWO workgroups per compute unit
+#define SDSM_K1B_EMAX 7168         //   (between class 1 and class 2, whose 157 KB leave one workgroup per compute unit: regions of ~5-15 k pixels, M ~ 100-250)
+#define SDSM_K2B_NMAX 512          // solve class 2b: 6 + M <= 512 and envelope <= 15300 doubles: the LDS that class 2 spends on vectors of 1024 unknowns
+#define SDSM_K2B_EMAX 15300        //   holds a larger envelope instead (~ 160 KB): keeps most of what class 2 cannot hold out of the global-memory class
 // Very large regions are solved by a GROUP of workgroups (2 .. 8, one per 8192 pixels): each takes a slice of the pixels in
 // every pass and the partial sums / gradient / Hessian are all-reduced through global memory (sdsm_solve.hip, WIDE).
 #define SDSM_WIDE_MIN_PIXELS 12288
@@ -39,17 +39,18 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_WIDE_FCAP 4104         // of them for the psi-type sums of the member's super-chunks (1 count + 4 * 1024 + pad: slices of up to 2 M pixels)
 #define SDSM_WIDE_PBUF (SDSM_K2_EMAX + SDSM_MAX_N_SOLVE + 64 + SDSM_WIDE_FCAP)   // doubles one workgroup publishes per exchange
 #define SDSM_WIDE_PIXELS 3072       // latency mode: larger regions go to class 2 (512 threads per candidate; a batch is as slow as its slowest candidate)
-#define SDSM_K2_EMAX 10300         // solve class 2: 6 + M <= SDSM_MAX_N_SOLVE and envelope <= 10300 doubles (LDS ~ 157 KB)
+#define SDSM_K2_EMAX 11000         // solve class 2: 6 + M <= SDSM_MAX_N_SOLVE and envelope <= 11000 doubles (LDS ~ 159 KB)
 #define SDSM_K1_DENSE_N 70         // 6 + M <= 70: even a dense triangle fits class 1
-#define SDSM_ENV_DENSE_N 142       // 6 + M <= 142: even a dense triangle fits class 2
+#define SDSM_ENV_DENSE_N 146       // 6 + M <= 146: even a dense triangle fits class 2
 #define SDSM_RUN 4                  // pixels per run: the region pixels of one image row inside one aligned 4-column cell share a G~ index list
 #define SDSM_MAX_ELL_GROUPS 256    // classes of the counting sort of the runs by their number of G~ entries (zcap_run <= 1024: classes of 4 beyond 256)
 #define SDSM_HZREG 8                // leading ('significant') entries of a run the solve kernel keeps in registers for the approximate Hessian
-#define SDSM_MSLOTS 32              // lane slots (lane & 31) of the fixed-point moment accumulators in LDS
+#define SDSM_MSLOTS 16              // lane slots (lane & 15) of the fixed-point moment accumulators in LDS (21 moments x 2 words each)
 #define SDSM_SUPER 8                // chunks (of 64 runs) per super-chunk: psi = sequential sum over super-chunks of the sequential sum of their chunk totals
 #ifndef SDSM_PANEL
 #define SDSM_PANEL 4               // columns per panel (8 measured slower: 195 k vs 200 k solves/s); of the envelope Cholesky; first stored columns are multiples of it
 #endif
+#define SDSM_SETUP_SMALL_PIXELS 4096   // two-launch setup: regions of at most this many pixels (that fit its tables) are set up by the 256-thread class
 #define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the largest solve class (Hessian + factor in global memory)
 
 #ifdef SDSM_PROFILE
@@ -111,6 +112,7 @@ struct ImageRef {
 
 struct BatchParams {
     int32_t n, n_images;
+    int32_t n_total, pad_n;            // candidates of the plan (n is the length of the launch list of a kernel)
     ImageRef img[SDSM_MAX_IMAGES];
     int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, bound on the entries of one pixel's row of G~
     int32_t zcap_run, zshift;          // bound on the entries of a run (union of <= 4 rows); sort class of a run = (entries + (1 << zshift) - 1) >> zshift
@@ -154,10 +156,34 @@ struct BatchParams {
     double *wide_pool;                 // sync words and all-reduce buffers of the workgroup groups (CandDesc.wide_off)
     int32_t *wide_ticket;              // [0]: next entry of the group launch list (members are claimed in the order in which workgroups START, see sdsm_solve.hip)
     long long wide_timeout;            // ticks of the 100 MHz wall clock a group member waits for its partners before the group is given up
+    // Work lists of the solve classes beyond class 1, built ON THE DEVICE: the host only knows an upper bound of M, the setup kernel knows
+    // M and the envelope, appends every candidate to the list of its class (sdsm_solve_class) and the class kernels -- a bounded number
+    // of resident workgroups each -- pop candidates until their list is empty.  cls_count: [l] entries of list l, [8 + l] next entry to
+    // pop; lists: 1b, 2, 2b, 3 (global memory).  cls_list: SDSM_NLISTS lists of n entries.
+    int32_t *cls_count;
+    int32_t *cls_list;
     double *hglob;                     // Hessian pool of the global-memory class (envelope too large for LDS), CandDesc.hglob_off
     long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 16 cycle counters per candidate (solve kernel)
     long long *prof2;                  // diagnostic build only: 8 cycle counters per candidate (setup kernel), behind the 16 n solve counters
 };
+
+// Solve class of a candidate once its setup is complete: the FIRST class whose limits (6 + M <= NMAX, Hessian envelope <= EMAX
+// doubles, region <= k1_pixmax pixels for the 256-thread classes) it meets.  Results do not depend on the class.
+enum { SDSM_CLS_NONE = -1, SDSM_CLS_1 = 0, SDSM_CLS_1B = 1, SDSM_CLS_2 = 2, SDSM_CLS_2B = 3, SDSM_CLS_3 = 4, SDSM_CLS_WIDE = 5 };
+#define SDSM_NLISTS 4               // 1b, 2, 2b, 3
+__host__ __device__ __forceinline__ int sdsm_solve_class(int status, int M, int env_size, int N, int wide_g, int k1_pixmax)
+{
+    if (status != ST_OK) return SDSM_CLS_NONE;
+    int Mfull = M;
+    if (6 + Mfull > SDSM_MAX_N_SOLVE) Mfull = 0;                             // elliptical result only (flagged unsupported)
+    const int nfull = 6 + Mfull, efull = Mfull > 0 ? env_size : 21;
+    if (wide_g > 0 && nfull <= SDSM_MAX_N_SOLVE && efull <= SDSM_K2_EMAX) return SDSM_CLS_WIDE;
+    if (nfull <= SDSM_K1_NMAX && efull <= SDSM_K1_EMAX && N <= k1_pixmax) return SDSM_CLS_1;
+    if (nfull <= SDSM_K1B_NMAX && efull <= SDSM_K1B_EMAX && N <= k1_pixmax) return SDSM_CLS_1B;
+    if (nfull <= SDSM_MAX_N_SOLVE && efull <= SDSM_K2_EMAX) return SDSM_CLS_2;
+    if (nfull <= SDSM_K2B_NMAX && efull <= SDSM_K2B_EMAX) return SDSM_CLS_2B;
+    return SDSM_CLS_3;
+}
 
 // ---------------------------------------------------------------------------------------------
 // workgroup primitives

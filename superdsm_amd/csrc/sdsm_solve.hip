@@ -77,7 +77,7 @@ struct Lay {
     static constexpr bool GLOBAL_H = GLOBALH;      // Hessian in global memory (envelope larger than LDS)
     static constexpr int W = NMAX + 2;             // vectors are indexed up to n (right-hand-side row) inclusive
     static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
-    static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, MS = FLAG + 2, IB = MS + 21 * NSLOT;   // MS: fixed-point moment accumulators, 21 sums x NSLOT lane slots
+    static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, MS = FLAG + 2, IB = MS + 42 * NSLOT;   // MS: fixed-point moment accumulators, 21 sums x 2 words x NSLOT lane slots
     static constexpr int NPANEL = NMAX / SDSM_PANEL + 2;
     static constexpr int IB_DOUBLES = (2 * W + NPANEL + 1) / 2;      // int arrays: rb[W], fst[W], rend[NPANEL]
     static constexpr int HP = IB + IB_DOUBLES;
@@ -707,6 +707,24 @@ __device__ __forceinline__ void fx_commit(double *addr, double s, int chi)
     atomicAdd(reinterpret_cast<unsigned long long *>(addr), v);
 }
 __device__ __forceinline__ void fx_add(double *addr, double a, double b, int chi) { fx_commit(addr, fma(a, b, fx_const(chi)), chi); }
+// The same to 96 bits: the product rounded to the unit goes to addr[0 ..], its exact remainder in units of 2^-48 of the unit to
+// addr[NSLOT ..].  For the coordinate moments of the polynomial part: theta has no regulariser, its gradient is a difference of
+// large sums and the curvature of a nearly separable region comes from pixels whose weights span many orders of magnitude --
+// a single 48-bit word below the LARGEST possible term (not the largest actual one: |y| is small where theta^ is large) lost 3-4
+// digits against the reference's float64 sums there, and a handful of such solves ran into the iteration cap.
+#define FX_LO_SHIFT 48
+__device__ __forceinline__ void fx_add2(double *addr, double a, double b, int chi)
+{
+    const double c1 = fx_const(chi);
+    const double s1 = fma(a, b, c1);
+    const double res = fma(a, b, c1 - s1);                   // a b - (s1 - c1): exact to 2^-53 of itself, |res| <= unit / 2
+    fx_commit(addr, s1, chi);
+    fx_commit(addr + NSLOT, res + fx_const(chi - (FX_LO_SHIFT << 20)), chi - (FX_LO_SHIFT << 20));
+}
+__device__ __forceinline__ double fx_get2(double hi, double lo, double unit)
+{
+    return fma((double)__double_as_longlong(lo), unit * (1.0 / 281474976710656.0), (double)__double_as_longlong(hi) * unit);
+}
 __device__ __forceinline__ double fx_unit(int chi) { return __hiloint2double((chi & 0x7ff00000) - (52 << 20), 0); }
 __device__ __forceinline__ double fx_get(double raw, double unit) { return (double)__double_as_longlong(raw) * unit; }
 
@@ -730,12 +748,12 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
     const int esz = M > 0 ? c.env_size : 21;
     for (int e = tid; e < esz; e += L::WGS) Hp[e] = 0;
     for (int i = tid; i < n; i += L::WGS) g[i] = 0;
-    for (int e = tid; e < 21 * NSLOT; e += L::WGS) msl[e] = 0;
+    for (int e = tid; e < 42 * NSLOT; e += L::WGS) msl[e] = 0;
     __syncthreads();
     int rbt[6];                                          // the 6 dense theta rows (uniform)
 #pragma unroll
     for (int b = 0; b < 6; b++) rbt[b] = M > 0 ? __builtin_amdgcn_readfirstlane(rbp[M + b]) : 0;
-    double *ms = reinterpret_cast<double *>(msl + (tid & (NSLOT - 1)));     // this lane's slot: moment m at ms[(m - 1) * NSLOT]
+    double *ms = reinterpret_cast<double *>(msl + (tid & (NSLOT - 1)));     // this lane's slot: moment m at ms[2 (m - 1) NSLOT] (high word) and ms[(2 (m - 1) + 1) NSLOT]
     const bool hfast = c.hzmax <= HZREG;
     double tot[1];
     run_pass<L, 1>(c, tot, [&](int p, bool active, double (&pv)[1]) {
@@ -772,13 +790,13 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
         {
             const int cg = fxg_hi, ch = fxh_hi;
             const double u3 = uu * u, u4 = uu * uu;
-            fx_add(ms + 0 * NSLOT, R0, 1.0, cg); fx_add(ms + 1 * NSLOT, R0, u, cg); fx_add(ms + 2 * NSLOT, R1, 1.0, cg);
-            fx_add(ms + 3 * NSLOT, R0, uu, cg); fx_add(ms + 4 * NSLOT, R1, u, cg); fx_add(ms + 5 * NSLOT, R2, 1.0, cg);
-            fx_add(ms + 6 * NSLOT, D0, 1.0, ch); fx_add(ms + 7 * NSLOT, D0, u, ch); fx_add(ms + 8 * NSLOT, D1, 1.0, ch);
-            fx_add(ms + 9 * NSLOT, D0, uu, ch); fx_add(ms + 10 * NSLOT, D1, u, ch); fx_add(ms + 11 * NSLOT, D2, 1.0, ch);
-            fx_add(ms + 12 * NSLOT, D0, u3, ch); fx_add(ms + 13 * NSLOT, D1, uu, ch); fx_add(ms + 14 * NSLOT, D2, u, ch); fx_add(ms + 15 * NSLOT, D3, 1.0, ch);
-            fx_add(ms + 16 * NSLOT, D0, u4, ch); fx_add(ms + 17 * NSLOT, D1, u3, ch); fx_add(ms + 18 * NSLOT, D2, uu, ch); fx_add(ms + 19 * NSLOT, D3, u, ch);
-            fx_add(ms + 20 * NSLOT, D4, 1.0, ch);
+            fx_add2(ms + 0 * NSLOT, R0, 1.0, cg); fx_add2(ms + 2 * NSLOT, R0, u, cg); fx_add2(ms + 4 * NSLOT, R1, 1.0, cg);
+            fx_add2(ms + 6 * NSLOT, R0, uu, cg); fx_add2(ms + 8 * NSLOT, R1, u, cg); fx_add2(ms + 10 * NSLOT, R2, 1.0, cg);
+            fx_add2(ms + 12 * NSLOT, D0, 1.0, ch); fx_add2(ms + 14 * NSLOT, D0, u, ch); fx_add2(ms + 16 * NSLOT, D1, 1.0, ch);
+            fx_add2(ms + 18 * NSLOT, D0, uu, ch); fx_add2(ms + 20 * NSLOT, D1, u, ch); fx_add2(ms + 22 * NSLOT, D2, 1.0, ch);
+            fx_add2(ms + 24 * NSLOT, D0, u3, ch); fx_add2(ms + 26 * NSLOT, D1, uu, ch); fx_add2(ms + 28 * NSLOT, D2, u, ch); fx_add2(ms + 30 * NSLOT, D3, 1.0, ch);
+            fx_add2(ms + 32 * NSLOT, D0, u4, ch); fx_add2(ms + 34 * NSLOT, D1, u3, ch); fx_add2(ms + 36 * NSLOT, D2, uu, ch); fx_add2(ms + 38 * NSLOT, D3, u, ch);
+            fx_add2(ms + 40 * NSLOT, D4, 1.0, ch);
         }
         if (M == 0 || !anynz) return;
         // xi part.  Gradient: every entry of the run; Hessian: its leading entries (kept in registers as they pass by)
@@ -882,21 +900,21 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
     PROF_ADD(0, pt);
     // totals of the moment slots (integers: any order), as raw integers for the exchange of a workgroup group
     unsigned long long *mraw = reinterpret_cast<unsigned long long *>(SD + L::RED);
-    double *tot22 = SD + L::RED + 32;
-    if (tid < 21) {
+    double *tot22 = SD + L::RED + 48;
+    if (tid < 42) {
         unsigned long long sacc = 0;
         for (int i = 0; i < NSLOT; i++) sacc += msl[tid * NSLOT + i];
         mraw[tid] = sacc;
     }
     __syncthreads();
-    if (c.wG > 1) wide_finish<L, 1>(c, tot, Hp, M > 0 ? c.env_size : 0, g + 6, M, reinterpret_cast<double *>(mraw), 21);
+    if (c.wG > 1) wide_finish<L, 1>(c, tot, Hp, M > 0 ? c.env_size : 0, g + 6, M, reinterpret_cast<double *>(mraw), 42);
     {
         const double uh = fx_unit(fxh_hi), ug = fx_unit(fxg_hi);
         if (M > 0) {
             for (int e = tid; e < c.env_size; e += L::WGS) Hp[e] = fx_get(Hp[e], uh);
             for (int i = 6 + tid; i < n; i += L::WGS) g[i] = fx_get(g[i], ug);
         }
-        if (tid < 21) tot22[1 + tid] = fx_get(reinterpret_cast<double *>(mraw)[tid], tid < 6 ? ug : uh);
+        if (tid < 21) tot22[1 + tid] = fx_get2(reinterpret_cast<double *>(mraw)[2 * tid], reinterpret_cast<double *>(mraw)[2 * tid + 1], tid < 6 ? ug : uh);
     }
     __syncthreads();
     if (tid < 6) g[tid] = moment_grad(tot22, tid);
@@ -1415,32 +1433,16 @@ __device__ __forceinline__ Frame make_frame(const Cand &c, int H, int W)
 
 }  // namespace
 
-// A candidate belongs to the FIRST class (1, 1b, 2, 2b, global memory) whose limits (6 + M <= NMAX and Hessian envelope <= EMAX
-// doubles) it meets; the limits of the previous class(es) are passed at run time (nprev = 0 for the first class).  The first class also writes the
-// records of trivial / failed-setup candidates.
+// One candidate, start to finish, by one workgroup.  A candidate belongs to the FIRST class (1, 1b, 2, 2b, global memory) whose limits
+// (6 + M <= NMAX and Hessian envelope <= EMAX doubles) it meets (sdsm_solve_class); a workgroup of class CLS leaves the others alone.
+// Class 1 (host-built launch list: all candidates, largest first) also writes the records of trivial / failed-setup candidates.
 // WIDE: the launch list holds (candidate | member << 24) for every member of every workgroup group.
-template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false>
-__global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records,
-                                                              uint32_t *masks, double *xi_out, int nprev2, int eprev2)
+// accept_any: the sweep of the "late" list by the global-memory class (any class beyond 1).
+template <int NMAX, int EMAX, bool GLOBALH, int WGSIZE, bool WIDE, int CLS>
+__device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, int wg, int handles_rest, bool accept_any, sdsm_record *records, uint32_t *masks, double *xi_out)
 {
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
-    // Issue priority: the passes over the pixels run at 0, everything between them -- reductions, the Newton bookkeeping, mask tail --
-    // at 2 and the factorisation at 3: the serial sections of a candidate (dependent LDS round trips, barriers) go first when a SIMD
-    // picks an instruction, the pixel passes of the other candidates of the compute unit fill the gaps (+2 % on the 8-image launch).
-    __builtin_amdgcn_s_setprio(2);
     int tid = threadIdx.x;                                   // re-derived (opaque_tid) at the start of every section: nothing per-thread is kept across the solver
-    int slot = blockIdx.x;
-    if (WIDE) {                                              // members are claimed in start order, not by workgroup index (see wide_barrier)
-        int *tk = reinterpret_cast<int *>(SD + L::FLAG);
-        if (tid == 0) *tk = __hip_atomic_fetch_add(P.wide_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        slot = uni(*tk);
-        __syncthreads();
-        if (slot >= P.n) return;                             // cannot happen: one ticket per workgroup of the launch
-    }
-    const int entry = uni(P.order[slot]);
-    const int ci = WIDE ? entry & 0xffffff : entry;
-    const int wg = WIDE ? (entry >> 24) & 0xff : 0;
     const CandDesc cd = uniform_desc(P.cand[ci]);
     const CandState st = uniform_state(P.state[ci]);
     sdsm_record *rec = &records[ci];
@@ -1457,16 +1459,10 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     int Mfull = st.M;
     bool unsupported = false;
     if (6 + Mfull > SDSM_MAX_N_SOLVE) { unsupported = true; Mfull = 0; }     // elliptical result only (flagged)
-    const int nfull = 6 + Mfull;
     const int efull = Mfull > 0 ? st.env_size : 21;
-    if (WIDE) {
-        if (!(nfull <= NMAX && efull <= EMAX)) return;                       // its envelope does not fit: left to the global-memory class
-    } else {
-        const bool to_group = cd.wide_g > 0 && nfull <= SDSM_MAX_N_SOLVE && efull <= SDSM_K2_EMAX;
-        if (to_group) return;                                                // solved by its workgroup group
-        if (nfull <= nprev && efull <= eprev && cd.N <= pixprev) return;     // an earlier class took it
-        if (nfull <= nprev2 && efull <= eprev2) return;                      // (the limits of classes 2 and 2b are not nested: the class after them checks both)
-        if (!(nfull <= NMAX && efull <= EMAX && cd.N <= pixmax)) return;     // a later class takes it
+    {
+        const int cls = sdsm_solve_class(st.status, st.M, st.env_size, cd.N, cd.wide_g, P.k1_pixmax);
+        if (accept_any ? !(cls >= SDSM_CLS_1B && cls <= SDSM_CLS_3) : cls != CLS) return;
     }
     if (GLOBALH && cd.hglob_off < 0) {                          // cannot happen (the host reserves a slot whenever Mcap admits it)
         if (tid == 0) { sdsm_record r0 = {}; r0.status = SDSM_CAND_UNSUPPORTED; r0.n_pixels = cd.N; r0.n_deform = st.M; *rec = r0; }
@@ -1702,6 +1698,46 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int n
     }
 }
 
+// The kernels.  LIST < 0: workgroup b takes entry b of the launch list P.order (class 1: all candidates, largest first; the workgroup
+// groups: their members, by ticket).  LIST >= 0: a bounded number of resident workgroups pop candidates from the device-built work list
+// of their class until it is empty (BatchParams.cls_count / cls_list, filled by the setup kernels) -- the host knows only an upper
+// bound of M and cannot tell how many candidates a class has; launching the bound (thousands of 512-thread workgroups that exit at once
+// but each need a whole free compute unit first) kept three hardware queues busy for milliseconds.
+template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false, int CLS = SDSM_CLS_1>
+__global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, int list)
+{
+    using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
+    // Issue priority: the passes over the pixels run at 0, everything between them -- reductions, the Newton bookkeeping, mask tail --
+    // at 2 and the factorisation at 3: the serial sections of a candidate (dependent LDS round trips, barriers) go first when a SIMD
+    // picks an instruction, the pixel passes of the other candidates of the compute unit fill the gaps (+2 % on the 8-image launch).
+    __builtin_amdgcn_s_setprio(2);
+    const int tid = threadIdx.x;
+    if (list >= 0) {
+        int *sh = reinterpret_cast<int *>(SD + L::FLAG);
+        for (;;) {
+            __syncthreads();                                     // (the previous candidate is finished by all threads)
+            if (tid == 0) *sh = __hip_atomic_fetch_add(&P.cls_count[8 + list], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int i = uni(*sh);
+            if (i >= uni(P.cls_count[list])) return;
+            const int ci = uni(P.cls_list[(size_t)list * P.n_total + i]);
+            __syncthreads();
+            solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, false, CLS>(P, ci, 0, 0, false, records, masks, xi_out);
+        }
+    }
+    int slot = blockIdx.x;
+    if (WIDE) {                                              // members are claimed in start order, not by workgroup index (see wide_barrier)
+        int *tk = reinterpret_cast<int *>(SD + L::FLAG);
+        if (tid == 0) *tk = __hip_atomic_fetch_add(P.wide_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        slot = uni(*tk);
+        __syncthreads();
+        if (slot >= P.n) return;                             // cannot happen: one ticket per workgroup of the launch
+    }
+    const int entry = uni(P.order[slot]);
+    solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, WIDE, WIDE ? SDSM_CLS_WIDE : CLS>(P, WIDE ? entry & 0xffffff : entry, WIDE ? (entry >> 24) & 0xff : 0, handles_rest, false, records, masks, xi_out);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Point evaluation for parity tests (sdsm_batch_eval): psi, gradient and the polynomial block of the Hessian at
 // caller-given parameters, computed by the SAME evaluators the solver uses (eval_full: loss_terms;
@@ -1823,7 +1859,7 @@ extern "C" hipError_t sdsm_launch_eval(const BatchParams &P, const double *param
 
 // ---- launch helper (called from sdsm_api.hip) ----------------------------------------------------
 // class 1:  6 + M <= 128,  envelope <= 2560 doubles, <= P.k1_pixmax pixels   256 threads, LDS ~ 30 KB  (three workgroups / CU)
-// class 1b: 6 + M <= 256,  envelope <= 6144 doubles, <= P.k1_pixmax pixels   256 threads, LDS ~ 68 KB  (two workgroups / CU; 512-thread kernels need
+// class 1b: 6 + M <= 256,  envelope <= 7168 doubles, <= P.k1_pixmax pixels   256 threads, LDS ~ 79 KB  (two workgroups / CU; 512-thread kernels need
 //           ~200 registers per thread, i.e. a whole compute unit per workgroup whatever their LDS)
 // class 2:  6 + M <= 1024, envelope <= 11000 doubles   512 threads, LDS ~ 157 KB (one workgroup / CU)
 // class 2b: 6 + M <= 512,  envelope <= 15900 doubles   512 threads, LDS ~ 160 KB (one workgroup / CU)
@@ -1832,11 +1868,10 @@ extern "C" hipError_t sdsm_launch_eval(const BatchParams &P, const double *param
 // image (10 073 candidates; 2695 of them beyond class 1, 122 beyond class 2) before classes 1b / 2b existed: class 2 alone needed
 // 10.9 s of workgroup time at ONE workgroup per compute unit (43 ms), and the global-memory class, queued behind it on the same
 // stream, another 75 ms (52 ms per candidate: every atomic of the pixel pass goes to memory).
-template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false>
-static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int pixprev, int pixmax, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
-                               int nprev2 = 0, int eprev2 = 0)
+template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false, int CLS = SDSM_CLS_1>
+static hipError_t launch_class(const BatchParams &P, int grid, int list, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream)
 {
-    auto kern = sdsm_k_solve<NMAX, EMAX, WPE, GLOBALH, WGSIZE, WIDE>;
+    auto kern = sdsm_k_solve<NMAX, EMAX, WPE, GLOBALH, WGSIZE, WIDE, CLS>;
     constexpr int lds = Lay<NMAX, EMAX, GLOBALH, WGSIZE>::TOTAL_BYTES;
     static_assert(lds <= 160 * 1024 - 512, "LDS budget");
     static bool attr_set[64] = {};                       // per instantiation and device; the attribute belongs to the function, not to the launch
@@ -1847,57 +1882,69 @@ static hipError_t launch_class(const BatchParams &P, int nprev, int eprev, int p
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    if (P.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(P.n), dim3(WGSIZE), lds, stream, P, nprev, eprev, pixprev, pixmax, handles_rest, records, masks, xi_out, nprev2, eprev2);
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WGSIZE), lds, stream, P, handles_rest, records, masks, xi_out, list);
     return hipGetLastError();
 }
+
+extern "C" hipError_t sdsm_launch_setup_rows(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w);
+
+#define SDSM_RESIDENT_512 256       // workgroups of a 512-thread class that pop from its work list: one per compute unit
+#define SDSM_RESIDENT_1B 512        // class 1b: two per compute unit
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
                                         hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */,
                                         int n_c, int n_d, int n_w)
 {
     hipError_t e;
-    // launch lists: P.order = [all n | the n_c candidates whose bound Mcap admits more than class 1 | the n_d that admit more than class 2]
-    BatchParams Pc = P, Pd = P, Pw = P;
-    Pc.order = P.order + P.n; Pc.n = n_c;
-    Pd.order = P.order + P.n + n_c; Pd.n = n_d;
-    Pw.order = P.order + P.n + n_c + n_d; Pw.n = n_w;                         // (candidate | member << 24) of the workgroup groups
+    // P.order = [all n, largest first | n_c candidates whose bound Mcap admits more than class 1 | the n_d that admit more than class 2 |
+    // (candidate | member << 24) of the workgroup groups].  n_c / n_d only bound the lengths of the device-built work lists.
+    BatchParams Pw = P;
+    Pw.order = P.order + P.n + n_c + n_d; Pw.n = n_w;
+    const int g_c = n_c < SDSM_RESIDENT_512 ? n_c : SDSM_RESIDENT_512, g_d = n_d < SDSM_RESIDENT_512 ? n_d : SDSM_RESIDENT_512;
+    const int g_b = n_c < SDSM_RESIDENT_1B ? n_c : SDSM_RESIDENT_1B;
     // fork: the side streams wait for everything queued on the caller's stream so far (setup kernel)
     if (n_c > 0 || n_d > 0 || n_w > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
-    // Three queues, longest chains first on each (measured on the synthetic 4096^2 image; a fourth stream did not get a hardware queue
-    // of its own and waited behind another):
-    //   side1: the global-memory class (one candidate takes tens of milliseconds), then class 2b -- lists of the few candidates whose
-    //          bound on M admits them;
-    //   side2: the workgroup groups of the very large regions, then class 2;
-    //   caller's stream: class 1, then class 1b (both 256 threads per candidate, several workgroups per compute unit).
-    // The lists of the larger classes are upper bounds (the host knows a bound on M, not M): most of their workgroups exit at once.
-    if (n_d > 0) {
+    // Queues (kernels of one stream run one after the other; the longest chains first on each):
+    //   side1: rows of G~ of the very large regions (sdsm_k_setup_rows: their last members also put the regions whose envelope does not
+    //          fit a workgroup group on the class lists), then class 2b, class 2, the global-memory class -- resident workgroups popping
+    //          from the device-built lists of the classes (usually a handful of candidates; an empty list costs one look);
+    //   side2: the workgroup groups of the very large regions (behind the rows);
+    //   side3: class 1b (two workgroups per compute unit);
+    //   caller's stream: class 1 (all candidates in the host's order, largest first; the others leave at once).
+    // The driver maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with another stream in use by the caller a side
+    // stream may share a queue and wait behind its neighbour -- superdsm_amd sets the variable to 8 when it is imported first.
+    if (n_d > 0 || n_c > 0 || n_w > 0) {
         if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, INT_MAX, INT_MAX, 0, records, masks, xi_out, side1,
-                                                                                                              SDSM_K2B_NMAX, SDSM_K2B_EMAX)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512>(Pd, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, INT_MAX, INT_MAX, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if (n_w > 0) {
+            if ((e = sdsm_launch_setup_rows(P, side1, Pw.order, n_w)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ev[2], side1)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(side2, ev[2], 0)) != hipSuccess) return e;
+            if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true, SDSM_CLS_WIDE>(Pw, n_w, -1, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
+        }
+        if (n_d > 0 && (e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(P, g_d, 2, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if (n_c > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, false, SDSM_CLS_2>(P, g_c, 1, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if (n_d > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(P, g_d, 3, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
     }
-    if (n_w > 0 || n_c > 0) {
-        if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
-        if (n_w > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true>(Pw, 0, 0, 0, INT_MAX, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
-        if (n_c > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512>(Pc, SDSM_K1B_NMAX, SDSM_K1B_EMAX, P.k1_pixmax, INT_MAX, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
-        if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
+    if (n_c > 0) {
+        if ((e = hipStreamWaitEvent(side3, ev[0], 0)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, SDSM_K1B_WPE, false, SDSM_K1B_THREADS, false, SDSM_CLS_1B>(P, g_b, 0, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[3], side3)) != hipSuccess) return e;
     }
-    // class 1 runs THREE wavefronts per SIMD (168 registers, no scratch: the sparse pass loads the row of G~ twice instead of
-    // holding it across the loss evaluation).  Measured on the 8-image launch: 7.4 ms at two wavefronts (240 registers), 5.5 ms at
-    // three, 6.6 ms at four (128 registers: 36 spilled, in the line-search and atomics loops) -- the solver is latency bound and a
-    // third workgroup per compute unit fills its stalls.
+    // class 1 runs THREE wavefronts per SIMD (168 registers).  Measured on the 8-image launch of round 2: 7.4 ms at two wavefronts
+    // (240 registers), 5.5 ms at three, 6.6 ms at four (128 registers: 36 spilled) -- the solver is latency bound and a third workgroup
+    // per compute unit fills its stalls.
     // Throughput mode: 192 threads per candidate, FOUR workgroups per compute unit (the same twelve wavefronts; one more independent
-    // candidate per compute unit, whose barriers stall three wavefronts instead of four: 5.43 -> 5.10 ms on the 8-image launch).
+    // candidate per compute unit, whose barriers stall three wavefronts instead of four: 5.43 -> 5.10 ms on that launch).
     // Latency mode (one image at a time, a batch is as slow as its slowest candidate): 256 threads per candidate.
-    if (P.k1_pixmax == INT_MAX) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream);
-    else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3>(P, 0, 0, 0, P.k1_pixmax, 1, records, masks, xi_out, stream);
+    if (P.k1_pixmax == INT_MAX) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
+    else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
     if (e != hipSuccess) return e;
-    if (n_c > 0 && (e = launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, SDSM_K1B_WPE, false, SDSM_K1B_THREADS>(Pc, SDSM_K1_NMAX, SDSM_K1_EMAX, P.k1_pixmax, P.k1_pixmax, 0, records, masks, xi_out, stream)) != hipSuccess) return e;
     // join
-    if (n_d > 0 && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
-    if ((n_w > 0 || n_c > 0) && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
-    (void)side3;
+    if ((n_d > 0 || n_c > 0 || n_w > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
+    if (n_w > 0 && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
+    if (n_c > 0 && (e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
     return hipSuccess;
 }

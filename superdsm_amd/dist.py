@@ -79,12 +79,17 @@ class RecordGather:
         return out
 
 
-def _gpu_solve_local(image, footprints, cfg, mask_info):
+def _gpu_solve_local(image, footprints, cfg, mask_info, cache=None):
     """Default local solver of a shard: one engine batch on this rank's GPU.  Returns (records, masks) as uint8 DEVICE tensors
-    (nothing is copied to the host here); ``mask_info`` is what every rank expects the shard's mask boxes to be."""
+    (nothing is copied to the host here); ``mask_info`` is what every rank expects the shard's mask boxes to be.  ``cache`` (a dict
+    owned by a :class:`ShardedBatch`): the plan and workspace are built once and launched again by later steps."""
     from . import _capi, engine
-    batch = engine.Batch(image, footprints, cfg, latency_mode=True)
-    assert np.array_equal(batch.mask_info[:len(footprints)], mask_info), 'plan of the shard disagrees with the replicated layout'
+    batch = cache.get('batch') if cache is not None else None
+    if batch is None:
+        batch = engine.Batch(image, footprints, cfg, latency_mode=True)
+        assert np.array_equal(batch.mask_info[:len(footprints)], mask_info), 'plan of the shard disagrees with the replicated layout'
+        if cache is not None:
+            cache['batch'] = batch
     batch.launch()
     n = len(footprints)
     if n:
@@ -103,6 +108,9 @@ def _gpu_solve_local(image, footprints, cfg, mask_info):
                 batch.masks_dev[o:o + nb] = sub.masks_dev[so:so + nb]
             torch.cuda.current_stream().synchronize()                      # (sub's buffers are released on return)
     return batch.records_dev[:n * 128], batch.masks_dev, batch          # (the batch keeps the buffers alive)
+
+
+_gpu_solve_local.supports_cache = True
 
 
 def fragments_from_masks(records, mask_info, mask_offset, masks):
@@ -127,44 +135,75 @@ class Sharder:
         self.device = device
         self.solve_local = solve_local
 
+    def prepare(self, image, footprints, cfg):
+        """Host planning of ONE batch over the ranks (identical on all ranks, no communication): shards by cost, mask boxes and
+        payload sizes of every rank, this rank's engine batch.  Returns a :class:`ShardedBatch`; its ``step()`` is launch + the one
+        all-gather, ``results()`` unpacks the gathered block."""
+        return ShardedBatch(self, image, footprints, cfg)
+
     def solve(self, image, footprints, cfg):
-        from . import _capi, engine
-        n = len(footprints)
-        footprints = [sorted(int(a) for a in fp) for fp in footprints]
+        sb = self.prepare(image, footprints, cfg)
+        sb.step()
+        return sb.results()
+
+
+class ShardedBatch:
+    """One batch of candidates dealt to the ranks of a :class:`Sharder` (strong scaling: BASELINE.json configs[4]).  ``step()`` can be
+    repeated (a benchmark's timed loop): local solve of this rank's share, pack on the device, ONE all-gather."""
+
+    def __init__(self, sharder, image, footprints, cfg):
+        from . import engine
+        self.sh = sharder
+        self.n = len(footprints)
+        self.footprints = [sorted(int(a) for a in fp) for fp in footprints]
         area = np.asarray(image.atom_stats).reshape(-1, 6)[:, 0]
-        costs = [sum(int(area[a]) for a in fp if 0 < a < len(area)) for fp in footprints]
-        shards = shard_indices(costs, self.world)
+        costs = [sum(int(area[a]) for a in fp if 0 < a < len(area)) for fp in self.footprints]
+        self.shards = shard_indices(costs, sharder.world)
         # mask boxes of all candidates and with them every rank's payload size: host-only planning, identical on all ranks
-        mask_info = engine.plan_mask_boxes(image, footprints, cfg)
-        words = (mask_info[:, 2].astype(np.int64) * mask_info[:, 3] + 31) // 32
-        nrec = [128 * len(sh) for sh in shards]
-        nmask = [max(4, int(4 * words[sh].sum())) for sh in shards]       # (an empty plan still has a 4-byte mask buffer)
-        pad = max(a + b for a, b in zip(nrec, nmask))
-        mine = shards[self.rank]
-        res = self.solve_local(image, [footprints[i] for i in mine], cfg, mask_info[mine])
-        rec_t, mask_t = res[0], res[1]
-        dev = rec_t.device if self.device is None else torch.device(self.device)
-        send = torch.zeros(pad, dtype=torch.uint8, device=dev)
-        send[:nrec[self.rank]].copy_(rec_t.reshape(-1)[:nrec[self.rank]])
-        send[nrec[self.rank]:nrec[self.rank] + nmask[self.rank]].copy_(mask_t.reshape(-1)[:nmask[self.rank]])
-        recv = torch.empty(self.world * pad, dtype=torch.uint8, device=dev)
-        if dist.get_backend(self.group) == 'gloo' and send.is_cuda:          # rehearsal on one GPU: gloo moves host memory
-            hs, hr = send.cpu(), torch.empty(self.world * pad, dtype=torch.uint8)
-            dist.all_gather(list(hr.chunk(self.world)), hs, group=self.group)
-            host = hr.numpy()
+        self.mask_info = engine.plan_mask_boxes(image, self.footprints, cfg)
+        self.words = (self.mask_info[:, 2].astype(np.int64) * self.mask_info[:, 3] + 31) // 32
+        self.nrec = [128 * len(sh) for sh in self.shards]
+        self.nmask = [max(4, int(4 * self.words[sh].sum())) for sh in self.shards]       # (an empty plan still has a 4-byte mask buffer)
+        self.pad = max(a + b for a, b in zip(self.nrec, self.nmask))
+        self.image, self.cfg = image, cfg
+        self.mine = self.shards[sharder.rank]
+        self.local = None                                       # what solve_local returned last (keeps its buffers alive)
+        self._cache = {}
+        self.send = self.recv = self.host = None
+
+    def step(self):
+        sh = self.sh
+        r = sh.rank
+        extra = {'cache': self._cache} if getattr(sh.solve_local, 'supports_cache', False) else {}
+        self.local = sh.solve_local(self.image, [self.footprints[i] for i in self.mine], self.cfg, self.mask_info[self.mine], **extra)
+        rec_t, mask_t = self.local[0], self.local[1]
+        dev = rec_t.device if sh.device is None else torch.device(sh.device)
+        if self.send is None:
+            self.send = torch.zeros(self.pad, dtype=torch.uint8, device=dev)
+            self.recv = torch.empty(sh.world * self.pad, dtype=torch.uint8, device=dev)
+        self.send[:self.nrec[r]].copy_(rec_t.reshape(-1)[:self.nrec[r]])
+        self.send[self.nrec[r]:self.nrec[r] + self.nmask[r]].copy_(mask_t.reshape(-1)[:self.nmask[r]])
+        if dist.get_backend(sh.group) == 'gloo' and self.send.is_cuda:          # rehearsal on one GPU: gloo moves host memory
+            hs, hr = self.send.cpu(), torch.empty(sh.world * self.pad, dtype=torch.uint8)
+            dist.all_gather(list(hr.chunk(sh.world)), hs, group=sh.group)
+            self.host = hr.numpy()
         else:
-            dist.all_gather(list(recv.chunk(self.world)), send, group=self.group)   # the one collective of the batch
-            host = recv.cpu().numpy()
-        records = np.zeros(n, _capi.RECORD_DTYPE)
-        fragments = [None] * n
-        for r in range(self.world):
-            idx = shards[r]
+            dist.all_gather(list(self.recv.chunk(sh.world)), self.send, group=sh.group)   # the one collective of the batch
+            self.host = None
+
+    def results(self):
+        from . import _capi, engine
+        host = self.host if self.host is not None else self.recv.cpu().numpy()
+        records = np.zeros(self.n, _capi.RECORD_DTYPE)
+        fragments = [None] * self.n
+        for r in range(self.sh.world):
+            idx = self.shards[r]
             if len(idx) == 0:
                 continue
-            buf = host[r * pad:(r + 1) * pad]
-            rec = buf[:nrec[r]].view(_capi.RECORD_DTYPE)
-            ofs = np.concatenate([[0], np.cumsum(4 * words[idx])[:-1]]).astype(np.int64)
-            frs = engine.fragments_from_masks(rec, mask_info[idx], ofs, buf[nrec[r]:nrec[r] + nmask[r]])
+            buf = host[r * self.pad:(r + 1) * self.pad]
+            rec = buf[:self.nrec[r]].view(_capi.RECORD_DTYPE)
+            ofs = np.concatenate([[0], np.cumsum(4 * self.words[idx])[:-1]]).astype(np.int64)
+            frs = engine.fragments_from_masks(rec, self.mask_info[idx], ofs, buf[self.nrec[r]:self.nrec[r] + self.nmask[r]])
             records[idx] = rec
             for j, i in enumerate(idx):
                 fragments[i] = frs[j]

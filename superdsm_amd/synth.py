@@ -34,11 +34,16 @@ def random_layout(shape, n, radius, seed, min_sep=0.6, border=None):
     return out
 
 
-def bbbc039_like_layout(seed=1002):
-    """Ellipses at the centres/areas of one reference BBBC039 regression CSV (data file)."""
-    with open(os.path.join(_DATA_DIR, 'bbbc039_like_layout.json')) as fp:
-        spec = json.load(fp)
-    rng = np.random.default_rng(seed)
+def bbbc039_like_layout(seed=1002, index=0):
+    """Ellipses at the centres/areas of one reference BBBC039 regression CSV (data files: ``index`` 0 .. 7 picks one of eight of the
+    198 per-image object tables, 68 .. 170 objects; 0 is the layout every test uses)."""
+    if index == 0:
+        with open(os.path.join(_DATA_DIR, 'bbbc039_like_layout.json')) as fp:
+            spec = json.load(fp)
+    else:
+        with open(os.path.join(_DATA_DIR, 'bbbc039_like_layouts.json')) as fp:
+            spec = json.load(fp)['layouts'][index]
+    rng = np.random.default_rng(seed + 7919 * index)
     out = []
     for area, cx, cy in spec['objects']:
         r = math.sqrt(area / math.pi)

@@ -5,12 +5,14 @@ from . import synth
 from .atoms import AtomAdjacencyGraph
 
 
-def make_scene(workload='synthetic256', max_size=3, alpha_factor=None):
+def make_scene(workload='synthetic256', max_size=3, alpha_factor=None, layout_index=0):
     """Synthetic image -> y, atoms, adjacency graph, candidate footprints and the dsm/* hyper-parameters of the
-    BASELINE.json config the workload stands for."""
+    BASELINE.json config the workload stands for.  ``layout_index`` (bbbc039_like only): which of the
+    eight reference object tables places the nuclei."""
     spec = dict(synth.WORKLOADS[workload])
     if workload == 'bbbc039_like':
-        shape, layout = synth.bbbc039_like_layout(spec['seed'])
+        shape, layout = synth.bbbc039_like_layout(spec['seed'], layout_index)
+        spec['seed'] += 7919 * layout_index
         af = 0.00033 if alpha_factor is None else alpha_factor       # examples/BBBC039/task.json: AF_alpha
     else:
         shape = spec['shape']

@@ -187,3 +187,22 @@ def test_bench_ranks_per_gpu_starts_that_many_processes_per_card():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out['n_gpus'] == 1 and out['ms_per_step'] == 3.0 and out['config']['backend'] == 'gloo'      # MAX over the three ranks' (1 + rank)
+
+
+def test_bench_sharded_mode_deals_one_batch_and_gathers_once():
+    """`python bench.py --gpus 2 --mode sharded --dry-run`: the strong-scaling entry point of BASELINE.json configs[4] -- ONE batch dealt
+    to the ranks by cost (dist.shard_indices), one all-gather of the per-rank payloads -- rehearsed without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--mode', 'sharded', '--dry-run'],
+                         env=env, capture_output=True, timeout=180)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['scaling'] == 'strong' and out['config']['mode'] == 'sharded' and out['config']['ranks'] == 2
+    assert sum(out['config']['shard_sizes']) == 1000 and max(out['config']['shard_sizes']) - min(out['config']['shard_sizes']) <= 1
+    assert out['config']['devices_visible'] == 0

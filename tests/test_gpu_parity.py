@@ -788,6 +788,36 @@ def test_synthetic4096_matches_oracle(gpu):
         assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][j])
 
 
+@pytest.mark.parametrize('layout', [4, 6, 7])
+def test_further_bbbc039_layouts_every_candidate_matches_oracle(gpu, layout):
+    """Three more of the reference's BBBC039 object tables (488 / 655 / 855 candidates; 117 .. 170 objects, denser images with small
+    atoms whose regions are separable or nearly so): every candidate against the oracle -- energy, status, mask -- and the number
+    of passes over the pixels: a solve that wanders (lost digits in its sums) shows up there first."""
+    from oracle import oracle
+    from superdsm_amd import testing
+    scene = testing.make_scene('bbbc039_like', max_size=3, layout_index=layout)
+    fps = scene['footprints']
+    res = testing.solve_scene_gpu(scene)
+    recs = res['records']
+    orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], fps, scene['dsm_cfg'], nthreads=0)
+    np.testing.assert_array_equal(recs['n_pixels'], orecs['N'])
+    np.testing.assert_array_equal(recs['n_deform'], orecs['M'])
+    np.testing.assert_array_equal(recs['status'], orecs['status'])
+    ev = recs['evals_full'].astype(np.int64) + recs['evals_value']
+    assert (ev <= 2 * orecs['evals'] + 40).all(), np.flatnonzero(ev > 2 * orecs['evals'] + 40)
+    assert abs(int(ev.sum()) - int(orecs['evals'].sum())) <= 0.03 * orecs['evals'].sum()
+    for k in range(len(fps)):
+        if orecs['status'][k] == 2:
+            continue
+        tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
+        if orecs['energy'][k] < 1e-4 * orecs['N'][k] * np.log(2) and (orecs['energy'][k] < 1e-3 or np.abs(orecs['theta'][k]).max() > 1e9):
+            # separable (or all but): inf psi = 0 is not attained, the value is the stopping rule's -- "no energy" on both sides
+            assert recs['energy'][k] < 1e-4 * orecs['N'][k] * np.log(2), (k, recs['energy'][k], orecs['energy'][k])
+        else:
+            assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (k, recs['energy'][k], orecs['energy'][k])
+            assert testing.dice(res['fragments'][k][0], res['fragments'][k][1], orecs['fg_offset'][k], ofrags[k], scene['y'].shape) >= 0.999, k
+
+
 def test_bbbc039_like_every_candidate_matches_oracle(gpu):
     """BASELINE.json configs[1] stand-in at full size: all 501 candidates against the oracle (energies, status, masks)."""
     from oracle import oracle

@@ -1,26 +1,40 @@
 """Diagnostic (needs the -DSDSM_PROFILE build): candidates, workgroup time and sizes per solve class of one launch.
-usage: SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so python tools/class_stats.py <workload>"""
+usage: SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so python tools/class_stats.py <workload> [images]
+(bbbc039_like with images > 1: one plan over that many DIFFERENT BBBC039-like images, as bench.py's step)"""
 import ctypes as C, os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from superdsm_amd import _capi, engine, testing
-wl=sys.argv[1]
-scene=testing.make_scene(wl,max_size=3)
-fps=scene['footprints']
-img=engine.DeviceImage(scene['y'],None,scene['atoms'],scene['dsm_cfg']['background_margin'])
-batch=engine.Batch(img,fps,scene['dsm_cfg'])
-prof=torch.zeros(len(fps)*24,dtype=torch.int64,device='cuda')
+wl = sys.argv[1]
+nimg = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+scenes = [testing.make_scene(wl, max_size=3, layout_index=k % 8 if wl == 'bbbc039_like' else 0) for k in range(nimg)]
+fps = [fp for sc in scenes for fp in sc['footprints']]
+image_of = np.concatenate([np.full(len(sc['footprints']), k, np.int32) for k, sc in enumerate(scenes)])
+imgs = [engine.DeviceImage(sc['y'], None, sc['atoms'], sc['dsm_cfg']['background_margin']) for sc in scenes]
+batch = engine.Batch(imgs if nimg > 1 else imgs[0], fps, scenes[0]['dsm_cfg'], image_of=image_of if nimg > 1 else None)
+prof = torch.zeros(len(fps) * 24, dtype=torch.int64, device='cuda')
 _capi.lib().sdsm_set_debug_buffer(C.c_void_p(prof.data_ptr()))
-for _ in range(2): batch.launch()
+for _ in range(2):
+    batch.launch()
 torch.cuda.synchronize()
-recs=batch.records()
-ins=batch.inspect()
-env=np.array([d['env_size'] for d in ins]); n=recs['n_deform']+6; N=recs['n_pixels']
-p=prof.cpu().numpy()[:len(fps)*16].reshape(-1,16).astype(float)
-tot=p[:,5]/2.4e6
-wide=np.array([d.get('wide_g',0) for d in ins]) if 'wide_g' in ins[0] else np.zeros(len(fps),int)
-k1=(n<=128)&(env<=2560); k1b=~k1&(n<=256)&(env<=6144); k2=~k1&~k1b&(env<=11000); k2b=~k1&~k1b&~k2&(n<=512)&(env<=15900); k3=~k1&~k1b&~k2&~k2b
-grp=(N>12288)&(env<=11000)          # throughput mode: regions of more than 12 288 pixels whose envelope fits class 2 are solved by workgroup groups
-for nm,m in (('K1',k1&~grp),('K1b',k1b&~grp),('K2',k2&~grp),('K2b',k2b),('K3',k3),('groups',grp)):
-    if m.any(): print(nm,'cands',m.sum(),'sum ms %.1f'%tot[m].sum(),'median ms %.2f'%np.median(tot[m]),'max ms %.2f'%tot[m].max(),'M median',int(np.median(recs['n_deform'][m])),'M max',int(recs['n_deform'][m].max()),'env median',int(np.median(env[m])),'env max',env[m].max(),'N median',int(np.median(N[m])),'N max',int(N[m].max()))
-print('env percentiles', np.percentile(env,[50,75,90,95,99,100]).astype(int), 'n percentiles', np.percentile(n,[50,75,90,95,99,100]).astype(int))
+_capi.lib().sdsm_enable_kernel_timing(1)
+batch.launch()
+print('solve kernels of the launch: %.2f ms, setup %.2f ms' % (_capi.lib().sdsm_last_solve_kernel_ms(), _capi.lib().sdsm_last_setup_kernel_ms()))
+recs = batch.records()
+lay = np.zeros(16, np.int64)
+_capi.check(_capi.lib().sdsm_plan_layout(batch.plan, lay.ctypes.data_as(C.c_void_p)), 'layout')
+ws = batch.ws.cpu().numpy()
+state = ws[lay[1]:lay[1] + int(lay[14]) * batch.n].view(np.int32).reshape(batch.n, -1)
+env = state[:, 15].astype(np.int64); n = recs['n_deform'] + 6; N = recs['n_pixels']
+p = prof.cpu().numpy()[:len(fps) * 16].reshape(-1, 16).astype(float)
+tot = p[:, 5] / 2.4e6
+k1 = (n <= 128) & (env <= 2560); k1b = ~k1 & (n <= 256) & (env <= 7168); k2 = ~k1 & ~k1b & (env <= 11000); k2b = ~k1 & ~k1b & ~k2 & (n <= 512) & (env <= 15300); k3 = ~k1 & ~k1b & ~k2 & ~k2b
+grp = (N > 12288) & (env <= 11000)          # throughput mode: regions of more than 12 288 pixels whose envelope fits class 2 are solved by workgroup groups (while the member budget lasts)
+for nm, m in (('K1', k1 & ~grp), ('K1b', k1b & ~grp), ('K2', k2 & ~grp), ('K2b', k2b), ('K3', k3), ('groups', grp)):
+    if m.any():
+        print(nm, 'cands', m.sum(), 'sum ms %.1f' % tot[m].sum(), 'median ms %.2f' % np.median(tot[m]), 'max ms %.2f' % tot[m].max(), 'M median', int(np.median(recs['n_deform'][m])), 'M max', int(recs['n_deform'][m].max()),
+              'env median', int(np.median(env[m])), 'env max', env[m].max(), 'N median', int(np.median(N[m])), 'N max', int(N[m].max()))
+print('env percentiles', np.percentile(env, [50, 75, 90, 95, 99, 100]).astype(int), 'n percentiles', np.percentile(n, [50, 75, 90, 95, 99, 100]).astype(int))
+print('slowest candidates (ms, N, M, env, evals full/value, phases A / factor / line search):')
+for k in np.argsort(-tot)[:12]:
+    print('  %.2f  N=%d M=%d env=%d evals=%d/%d  A=%.2f fac=%.2f ls=%.2f' % (tot[k], N[k], recs['n_deform'][k], env[k], recs['evals_full'][k], recs['evals_value'][k], p[k, 0] / 2.4e6, p[k, 3] / 2.4e6, p[k, 4] / 2.4e6))
