@@ -136,7 +136,7 @@ struct sdsm_plan {
     std::vector<int64_t> mask_off_bytes, xi_off;
     int64_t total_pixels = 0, total_runs = 0, total_ell = 0, total_xi = 0, total_mask_words = 0, n_hglob = 0, n_wide = 0;
     size_t off_cand = 0, off_state = 0, off_fp = 0, off_order = 0, off_crop_y = 0, off_crop_rc = 0, off_crop_cc = 0, off_dist = 0, off_tmp_y = 0, off_tmp_rc = 0, off_inv = 0, off_run_meta = 0,
-           off_run_q0 = 0, off_run_aux = 0, off_grid = 0, off_ell_im = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, off_ticket = 0, off_cls_list = 0, total = 0;
+           off_run_q0 = 0, off_run_aux = 0, off_grid = 0, off_ell_im = 0, off_ell_w = 0, off_psf = 0, off_env_fst = 0, off_env_rb = 0, off_hglob = 0, off_wide = 0, off_ticket = 0, total = 0;
     // The launch lists and CandDesc.wide_* live in the workspace (sdsm_batch_upload): a layout change after the upload
     // (sdsm_plan_set_latency_mode) would leave stale tables on the device, so launches check the generation they were uploaded at.
     uint64_t layout_gen = 0;
@@ -166,7 +166,11 @@ static hipError_t acquire_sides(const sdsm_plan *p)
     }
     SideSet *s = new SideSet();
     s->device = dev;
-    for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking)) != hipSuccess) { delete s; return e; }
+    // high priority: the classes beyond 1 are few, long candidates (the end of a launch) whose 512-thread workgroups each need a whole
+    // compute unit; as units become free the dispatcher serves these queues before the thousands of small workgroups of class 1
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithPriority(&s->side[i], hipStreamNonBlocking, prio_high)) != hipSuccess) { delete s; return e; }
     for (int i = 0; i < 4; i++) if ((e = hipEventCreateWithFlags(&s->fj[i], hipEventDisableTiming)) != hipSuccess) { delete s; return e; }
     p->sides = s;
     return hipSuccess;
@@ -287,8 +291,7 @@ static void layout_plan(sdsm_plan *p)
     p->off_env_rb = take(4 * (size_t)std::max<int64_t>(p->total_xi, 1));
     p->off_hglob = take(8 * (size_t)std::max<int64_t>(p->n_hglob, 1));      // n_hglob counts doubles
     p->off_wide = take(8 * (size_t)std::max<int64_t>(p->n_wide, 1));        // n_wide counts doubles
-    p->off_ticket = take(256);                                                // [0] ticket of the workgroup groups; [16 ..] counters of the class work lists (zeroed before every launch)
-    p->off_cls_list = take(4 * (size_t)SDSM_NLISTS * std::max(n, 1));
+    p->off_ticket = take(256);                                                // [0] ticket of the workgroup groups; [16 ..] heads of the launch lists of the classes beyond 1 (zeroed before every launch)
     p->total = o;
 }
 extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, const int32_t *W, const int32_t *n_atoms, const int32_t *const *atom_stats,
@@ -477,7 +480,7 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
     P.env_fst = (int32_t *)(b + p->off_env_fst); P.env_rb = (int32_t *)(b + p->off_env_rb);
     P.hglob = (double *)(b + p->off_hglob); P.wide_pool = (double *)(b + p->off_wide);
     P.wide_ticket = (int32_t *)(b + p->off_ticket); P.wide_timeout = g_wide_timeout;
-    P.cls_count = (int32_t *)(b + p->off_ticket) + 16; P.cls_list = (int32_t *)(b + p->off_cls_list);
+    P.cls_count = (int32_t *)(b + p->off_ticket) + 16;
     P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
     return P;
 }

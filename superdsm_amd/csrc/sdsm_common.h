@@ -156,12 +156,7 @@ struct BatchParams {
     double *wide_pool;                 // sync words and all-reduce buffers of the workgroup groups (CandDesc.wide_off)
     int32_t *wide_ticket;              // [0]: next entry of the group launch list (members are claimed in the order in which workgroups START, see sdsm_solve.hip)
     long long wide_timeout;            // ticks of the 100 MHz wall clock a group member waits for its partners before the group is given up
-    // Work lists of the solve classes beyond class 1, built ON THE DEVICE: the host only knows an upper bound of M, the setup kernel knows
-    // M and the envelope, appends every candidate to the list of its class (sdsm_solve_class) and the class kernels -- a bounded number
-    // of resident workgroups each -- pop candidates until their list is empty.  cls_count: [l] entries of list l, [8 + l] next entry to
-    // pop; lists: 1b, 2, 2b, 3 (global memory).  cls_list: SDSM_NLISTS lists of n entries.
-    int32_t *cls_count;
-    int32_t *cls_list;
+    int32_t *cls_count;                // [l]: next entry of launch list l that a resident workgroup of a class beyond 1 takes (sdsm_k_solve; zeroed before every launch)
     double *hglob;                     // Hessian pool of the global-memory class (envelope too large for LDS), CandDesc.hglob_off
     long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 16 cycle counters per candidate (solve kernel)
     long long *prof2;                  // diagnostic build only: 8 cycle counters per candidate (setup kernel), behind the 16 n solve counters
@@ -170,7 +165,6 @@ struct BatchParams {
 // Solve class of a candidate once its setup is complete: the FIRST class whose limits (6 + M <= NMAX, Hessian envelope <= EMAX
 // doubles, region <= k1_pixmax pixels for the 256-thread classes) it meets.  Results do not depend on the class.
 enum { SDSM_CLS_NONE = -1, SDSM_CLS_1 = 0, SDSM_CLS_1B = 1, SDSM_CLS_2 = 2, SDSM_CLS_2B = 3, SDSM_CLS_3 = 4, SDSM_CLS_WIDE = 5 };
-#define SDSM_NLISTS 4               // 1b, 2, 2b, 3
 __host__ __device__ __forceinline__ int sdsm_solve_class(int status, int M, int env_size, int N, int wide_g, int k1_pixmax)
 {
     if (status != ST_OK) return SDSM_CLS_NONE;

@@ -93,20 +93,6 @@ __device__ __forceinline__ int cheb(int r0, int c0, int r1, int c1)
     return a > b ? a : b;
 }
 
-// The setup of candidate ci is complete (state written): append it to the work list of its solve class (class 1 and the workgroup
-// groups have host-built lists).  Also called by the last member of a wide-flagged region (sdsm_k_setup_rows) whose envelope turned out
-// too large for a workgroup group: the kernels of the classes it can then belong to (2, 2b, global memory) are queued behind
-// sdsm_k_setup_rows on the same stream.  One thread.
-__device__ __forceinline__ void publish_class(const BatchParams &P, const CandDesc &cd, int ci, int status, int M, int env_size, bool late)
-{
-    const int cls = sdsm_solve_class(status, M, env_size, cd.N, cd.wide_g, P.k1_pixmax);
-    if (cls < SDSM_CLS_1B || cls > SDSM_CLS_3) return;
-    (void)late;
-    const int l = cls - SDSM_CLS_1B;
-    const int slot = atomicAdd(&P.cls_count[l], 1);
-    P.cls_list[(size_t)l * P.n_total + slot] = ci;
-}
-
 // Multiplier of the low-discrepancy scatter of the runs: scan index of raster run rr = (rr * B) mod NR, B ~ 0.618 NR coprime to NR
 // (neighbouring positions are far apart in the image, which decorrelates the LDS atomics of the solve kernel).
 __device__ __forceinline__ uint32_t scatter_mult(uint32_t NR)
@@ -451,7 +437,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     if (null_matrix) {                                  // no G~: the final order of the runs is their scan order
         plain_runs(P, cd, NR, B, tid, T::WG);
         s.M = 0; s.status = ST_OK;
-        if (tid == 0) { *st = s; publish_class(P, cd, ci, s.status, 0, 21, false); }
+        if (tid == 0) *st = s;
         return;
     }
     __syncthreads();
@@ -556,7 +542,6 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     if (6 + M > SDSM_MAX_N_SOLVE) {                      // the solve kernel only computes the elliptical model (flagged unsupported)
         plain_runs(P, cd, NR, B, tid, T::WG);
         s.M = M; s.status = ST_OK;
-        if (tid == 0) publish_class(P, cd, ci, s.status, M, 21, false);
         if (tid == 0) *st = s;
         return;
     }
@@ -706,7 +691,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     if (tid == 0) s.env_size = envelope_from_first(P, cd, M, efirst);
     s.hzmax = hzmax;
     s.status = sh_err ? ST_ERROR : ST_OK;
-    if (tid == 0) { *st = s; publish_class(P, cd, ci, s.status, M, s.env_size, false); }
+    if (tid == 0) *st = s;
     SETUP_T(6);
 #ifdef SDSM_PROFILE
     if (P.prof2 && tid == 0) for (int k = 0; k < 8; k++) P.prof2[(size_t)ci * 8 + k] = sp_acc[k];
@@ -767,7 +752,6 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
     if (tid == 0) {
         st->env_size = envelope_from_first(P, cd, M, efirst);
         if (__hip_atomic_load(&sync[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) st->status = ST_ERROR;
-        publish_class(P, cd, ci, st->status, M, st->env_size, true);     // (only if its envelope does not fit a workgroup group)
     }
 }
 

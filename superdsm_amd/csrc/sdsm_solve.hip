@@ -1699,10 +1699,12 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
 }
 
 // The kernels.  LIST < 0: workgroup b takes entry b of the launch list P.order (class 1: all candidates, largest first; the workgroup
-// groups: their members, by ticket).  LIST >= 0: a bounded number of resident workgroups pop candidates from the device-built work list
-// of their class until it is empty (BatchParams.cls_count / cls_list, filled by the setup kernels) -- the host knows only an upper
-// bound of M and cannot tell how many candidates a class has; launching the bound (thousands of 512-thread workgroups that exit at once
-// but each need a whole free compute unit first) kept three hardware queues busy for milliseconds.
+// groups: their members, by ticket).  LIST >= 0 (the classes beyond 1): a bounded number of RESIDENT workgroups pop entries of the
+// launch list (head counter BatchParams.cls_count[LIST]) until it is exhausted and solve the candidates that belong to their class.
+// The host knows only an upper bound of M, so the lists of these classes are upper bounds -- candidates that COULD belong, largest
+// first; most do not.  One workgroup per entry meant thousands of 512-thread workgroups that exit at once but each need a whole free
+// compute unit first: they kept three hardware queues busy for milliseconds (and class 2b waited 4.5 ms behind the empty global-memory
+// class).  A resident workgroup drops a foreign entry in a microsecond.
 template <int NMAX, int EMAX, int WPE, bool GLOBALH = false, int WGSIZE = 256, bool WIDE = false, int CLS = SDSM_CLS_1>
 __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int handles_rest, sdsm_record *records, uint32_t *masks, double *xi_out, int list)
 {
@@ -1716,11 +1718,11 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int h
         int *sh = reinterpret_cast<int *>(SD + L::FLAG);
         for (;;) {
             __syncthreads();                                     // (the previous candidate is finished by all threads)
-            if (tid == 0) *sh = __hip_atomic_fetch_add(&P.cls_count[8 + list], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) *sh = __hip_atomic_fetch_add(&P.cls_count[list], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const int i = uni(*sh);
-            if (i >= uni(P.cls_count[list])) return;
-            const int ci = uni(P.cls_list[(size_t)list * P.n_total + i]);
+            if (i >= P.n) return;
+            const int ci = uni(P.order[i]);
             __syncthreads();
             solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, false, CLS>(P, ci, 0, 0, false, records, masks, xi_out);
         }
@@ -1889,7 +1891,21 @@ static hipError_t launch_class(const BatchParams &P, int grid, int list, int han
 
 extern "C" hipError_t sdsm_launch_setup_rows(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w);
 
-#define SDSM_RESIDENT_512 256       // workgroups of a 512-thread class that pop from its work list: one per compute unit
+// Head start of the classes beyond 1: one wavefront that waits `ticks` of the 100 MHz wall clock (see sdsm_launch_solve).
+__global__ void sdsm_k_head_start(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+#ifndef SDSM_HEAD_START_US
+#define SDSM_HEAD_START_US 60
+#endif
+
+// Resident workgroups of the classes beyond 1 (each pops entries of its launch list until the list is exhausted).  A 512-thread
+// workgroup needs a whole free compute unit and waits for one while class 1 floods the chip: no more of them than the class can use.
+#define SDSM_RESIDENT_2 256         // class 2: one per compute unit (synthetic 4096^2: hundreds of candidates)
+#define SDSM_RESIDENT_2B 128        // class 2b (synthetic 4096^2: 91 candidates)
+#define SDSM_RESIDENT_3 32          // global-memory class (31 there; usually none)
 #define SDSM_RESIDENT_1B 512        // class 1b: two per compute unit
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
@@ -1901,36 +1917,39 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     // (candidate | member << 24) of the workgroup groups].  n_c / n_d only bound the lengths of the device-built work lists.
     BatchParams Pw = P;
     Pw.order = P.order + P.n + n_c + n_d; Pw.n = n_w;
-    const int g_c = n_c < SDSM_RESIDENT_512 ? n_c : SDSM_RESIDENT_512, g_d = n_d < SDSM_RESIDENT_512 ? n_d : SDSM_RESIDENT_512;
+    BatchParams Pc = P, Pd = P;
+    Pc.order = P.order + P.n; Pc.n = n_c;
+    Pd.order = P.order + P.n + n_c; Pd.n = n_d;
+    const int g_c = n_c < SDSM_RESIDENT_2 ? n_c : SDSM_RESIDENT_2, g_d = n_d < SDSM_RESIDENT_2B ? n_d : SDSM_RESIDENT_2B, g_3 = n_d < SDSM_RESIDENT_3 ? n_d : SDSM_RESIDENT_3;
     const int g_b = n_c < SDSM_RESIDENT_1B ? n_c : SDSM_RESIDENT_1B;
-    // fork: the side streams wait for everything queued on the caller's stream so far (setup kernel)
+    // rows of G~ of the very large regions (one workgroup per member of their workgroup groups), on the caller's stream right behind the
+    // setup kernel: a region whose envelope turns out too large for a group belongs to class 2b or the global-memory class, whose kernels
+    // therefore wait for them too
+    if (n_w > 0 && (e = sdsm_launch_setup_rows(P, stream, Pw.order, n_w)) != hipSuccess) return e;
+    // fork: the side streams wait for everything queued on the caller's stream so far (setup kernels)
     if (n_c > 0 || n_d > 0 || n_w > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
     // Queues (kernels of one stream run one after the other; the longest chains first on each):
-    //   side1: rows of G~ of the very large regions (sdsm_k_setup_rows: their last members also put the regions whose envelope does not
-    //          fit a workgroup group on the class lists), then class 2b, class 2, the global-memory class -- resident workgroups popping
-    //          from the device-built lists of the classes (usually a handful of candidates; an empty list costs one look);
-    //   side2: the workgroup groups of the very large regions (behind the rows);
+    //   side1: the global-memory class (one candidate takes tens of milliseconds), then class 2b;
+    //   side2: the workgroup groups of the very large regions, then class 2;
     //   side3: class 1b (two workgroups per compute unit);
     //   caller's stream: class 1 (all candidates in the host's order, largest first; the others leave at once).
     // The driver maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with another stream in use by the caller a side
     // stream may share a queue and wait behind its neighbour -- superdsm_amd sets the variable to 8 when it is imported first.
-    if (n_d > 0 || n_c > 0 || n_w > 0) {
+    if (n_d > 0) {
         if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
-        if (n_w > 0) {
-            if ((e = sdsm_launch_setup_rows(P, side1, Pw.order, n_w)) != hipSuccess) return e;
-            if ((e = hipEventRecord(ev[2], side1)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(side2, ev[2], 0)) != hipSuccess) return e;
-            if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true, SDSM_CLS_WIDE>(Pw, n_w, -1, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
-            if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
-        }
-        if (n_d > 0 && (e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(P, g_d, 2, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-        if (n_c > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, false, SDSM_CLS_2>(P, g_c, 1, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-        if (n_d > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(P, g_d, 3, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(Pd, g_3, 3, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
+    }
+    if (n_w > 0 || n_c > 0) {
+        if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
+        if (n_w > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true, SDSM_CLS_WIDE>(Pw, n_w, -1, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
+        if (n_c > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, false, SDSM_CLS_2>(Pc, g_c, 1, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
     }
     if (n_c > 0) {
         if ((e = hipStreamWaitEvent(side3, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, SDSM_K1B_WPE, false, SDSM_K1B_THREADS, false, SDSM_CLS_1B>(P, g_b, 0, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
+        if ((e = launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, SDSM_K1B_WPE, false, SDSM_K1B_THREADS, false, SDSM_CLS_1B>(Pc, g_b, 0, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[3], side3)) != hipSuccess) return e;
     }
     // class 1 runs THREE wavefronts per SIMD (168 registers).  Measured on the 8-image launch of round 2: 7.4 ms at two wavefronts
@@ -1939,12 +1958,18 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     // Throughput mode: 192 threads per candidate, FOUR workgroups per compute unit (the same twelve wavefronts; one more independent
     // candidate per compute unit, whose barriers stall three wavefronts instead of four: 5.43 -> 5.10 ms on that launch).
     // Latency mode (one image at a time, a batch is as slow as its slowest candidate): 256 threads per candidate.
+    // Head start: a 512-thread workgroup needs a whole free compute unit, and once the thousands of small workgroups of class 1 flood
+    // the chip none becomes free before class 1 is through (kernel trace of 8 different BBBC039-like images: the global-memory class
+    // -- no candidates -- "ran" 5.4 ms, class 2b behind it started when class 1 ended, the groups took 9.7 ms instead of 4.7; stream
+    // priorities change nothing).  The few long candidates of the large classes ARE the end of the launch: class 1 starts some tens of
+    // microseconds after them -- their resident workgroups are in place by then, the ones without work gone again.
+    if (n_c > 0 || n_d > 0 || n_w > 0) hipLaunchKernelGGL(sdsm_k_head_start, dim3(1), dim3(64), 0, stream, (long long)SDSM_HEAD_START_US * 100);
     if (P.k1_pixmax == INT_MAX) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
     else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
     if (e != hipSuccess) return e;
     // join
-    if ((n_d > 0 || n_c > 0 || n_w > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
-    if (n_w > 0 && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
+    if (n_d > 0 && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
+    if ((n_w > 0 || n_c > 0) && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
     if (n_c > 0 && (e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
     return hipSuccess;
 }

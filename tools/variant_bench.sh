@@ -1,4 +1,4 @@
-for lib in libsdsm_hip.so libsdsm_hip_p8.so; do
+for lib in libsdsm_hip.so; do
   for wl in bbbc039_like gowt1_like synthetic4096; do
     SDSM_HIP_LIB=superdsm_amd/$lib timeout -k 10 200 python bench.py --workload $wl --no-cpu --no-extras --min-gpu-seconds 0.3 > gpurun_out/v_${lib}_$wl.json 2> gpurun_out/v_${lib}_$wl.err
     python -c "
