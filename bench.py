@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--mode', default='solves', choices=['solves', 'image_set', 'sharded'])
     ap.add_argument('--min-gpu-seconds', type=float, default=2.0, help='the timed regions are repeated until they add up to this much (so that an outside sampler of GPU activity sees the run)')
     ap.add_argument('--no-configs', action='store_true', help='skip the other BASELINE.json configs in extras')
+    ap.add_argument('--same-layout', action='store_true', help='the step of rounds 1-2: 8 copies of ONE BBBC039-like image (layout 0) instead of 8 different ones')
     ap.add_argument('--images', type=int, default=None, help='images per plan = per step (default: 8 for bbbc039_like / synthetic256, else 1)')
     ap.add_argument('--max-size', type=int, default=3, help='candidates = connected atom subsets up to this size + universes')
     ap.add_argument('--repeats', type=int, default=5, help='the timed region of --steps steps is repeated; the median is reported')
@@ -234,7 +235,7 @@ def main():
     n_images = args.images if args.images else (8 if args.workload in ('bbbc039_like', 'synthetic256') else 1)
     # `n_images` images per step; BBBC039-like: DIFFERENT images (eight of the reference's per-image object tables place the nuclei)
     scenes = [testing.make_scene(args.workload, max_size=args.max_size, layout_index=k % 8 if args.workload == 'bbbc039_like' else 0) for k in range(n_images)] \
-        if args.workload == 'bbbc039_like' else [testing.make_scene(args.workload, max_size=args.max_size)] * n_images
+        if args.workload == 'bbbc039_like' and not args.same_layout else [testing.make_scene(args.workload, max_size=args.max_size)] * n_images
     scene = scenes[0]
     fps1 = scene['footprints']
     margin = scene['dsm_cfg']['background_margin']
@@ -349,6 +350,11 @@ def main():
         dist.destroy_process_group()
 
 
+def _capi_lib():
+    from superdsm_amd import _capi
+    return _capi.lib()
+
+
 def extras(args, scene, img, n_images):
     """What BASELINE.json's metric names beside the solver throughput: wall clock per image through the product entry points."""
     import torch
@@ -412,6 +418,30 @@ def extras(args, scene, img, n_images):
         ex[f'stage_wall_ms_per_image_lockstep{n_images}'] = float(np.median(ts))
         ex['stage_pruning'] = pruning
         ex['stage_beta'] = beta
+    # (3b) the step of rounds 1-2 for comparison: ONE launch over 8 copies of this image (identical work per image, no large clusters)
+    if args.workload == 'bbbc039_like':
+        L = _capi_lib()
+        imgs8 = [engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin']) for _ in range(8)]
+        b8 = engine.Batch(imgs8, scene['footprints'] * 8, scene['dsm_cfg'], image_of=np.repeat(np.arange(8, dtype=np.int32), len(scene['footprints'])))
+        for _ in range(3):
+            b8.launch()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            b8.launch()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / 20 * 1e3
+        L.sdsm_enable_kernel_timing(1)
+        km = []
+        for _ in range(3):
+            b8.launch()
+            km.append(L.sdsm_last_solve_kernel_ms())
+        L.sdsm_enable_kernel_timing(0)
+        r8 = b8.records()
+        alg8 = engine.algorithmic_bytes(r8, b8.mask_info)
+        ex['step_of_rounds_1_2_eight_copies_of_one_image'] = dict(candidates=len(r8), ms_per_step=ms, candidate_solves_per_s=len(r8) / (ms * 1e-3), solve_kernels_ms=float(np.mean(km)),
+                                                                  roofline_frac=alg8 / (float(np.mean(km)) * 1e-3) / 8e12, algorithmic_bytes_per_launch=alg8,
+                                                                  note='round 2 reported 639 k solves/s, 5.06 ms solve kernel, 5.8 % on this step')
     # (4) preprocessing: 16 B / pixel algorithmic (read g, write y)
     rng = np.random.default_rng(0)
     pre = {}

@@ -41,8 +41,6 @@ for c in 'ABCD':
         print('   %-9s share of total: %.1f%%   per full eval (median): %.1f us' % (nm, 100 * p[m, i].sum() / tot.sum(), np.median(p[m, i] / np.maximum(recs['evals_full'][m], 1)) / 2400))
     print('   elliptical share: %.1f%%' % (100 * p[m, 6].sum() / tot.sum()))
 worst = np.argsort(-p[:, 5])[:8]
-if p[:, 8:13].sum() > 0:
-    print('fine sections of the sparse pixel pass (thread 0, fenced): loads %.1f%%  gather %.1f%%  loss+sums %.1f%%  grad atomics %.1f%%  hess atomics %.1f%%' % tuple(100 * p[:, 8:13].sum(0) / p[:, 8:13].sum()))
 if p[:, 13:16].sum() > 0:
     m = cls == 'B'
     print('factor_solve parts, class B, us per call (median): head %.1f  panels %.1f  l2 + back substitution %.1f' % (np.median(p[m, 13] / np.maximum(recs['iters_dsm'][m], 1)) / 2400, np.median((p[m, 8:12].sum(1) + p[m, 14]) / np.maximum(recs['iters_dsm'][m], 1)) / 2400, np.median(p[m, 15] / np.maximum(recs['iters_dsm'][m], 1)) / 2400))
