@@ -213,6 +213,11 @@ int sdsm_separable_filter(const double *d_in, int H, int W, const double *h_w0, 
 int sdsm_minsetcover(int n, int words, const uint64_t *footprints, const double *energies, double beta, int merge, int max_iter,
                      double gamma, int32_t *selected, int32_t *n_selected);
 int sdsm_maxsetpack(int n, int words, const uint64_t *footprints, const double *energies, int32_t *selected, int32_t *n_selected);
+/* sdsm_minsetcover for several independent families in one call (MinSetCover.update, superdsm/minsetcover.py:142-153: one cover per touched
+ * cluster): family f has n[f] objects of words[f] uint64; footprints / energies / selected of the families follow each other (n[f] *
+ * words[f] / n[f] / n[f] entries); n_selected[f] = size of family f's solution. */
+int sdsm_minsetcover_multi(int n_families, const int32_t *n, const int32_t *words, const uint64_t *footprints, const double *energies, double beta,
+                           int merge, int max_iter, double gamma, int32_t *selected, int32_t *n_selected);
 
 /* Host helper (no device access): size of the search space of the stage's iterations, per cluster -- what the reference's
  * _estimate_progress (superdsm/globalenergymin.py:310-323) enumerates footprint by footprint in Python from the generation of the

@@ -68,6 +68,7 @@ SYMBOLS = {
     'sdsm_separable_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'sdsm_separable_filter': (_i32, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     'sdsm_minsetcover': (_i32, [_i32, _i32, _vp, _vp, _f64, _i32, _i32, _f64, _vp, _vp]),
+    'sdsm_minsetcover_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _f64, _i32, _i32, _f64, _vp, _vp]),
     'sdsm_maxsetpack': (_i32, [_i32, _i32, _vp, _vp, _vp, _vp]),
     'sdsm_count_growth': (_i32, [_i32, _vp, _vp, _vp, _i32, _i64, _vp]),
     'sdsm_unpack_fragments': (_i64, [_vp, _vp, _vp, _vp, _i32, _vp, _vp]),

@@ -116,6 +116,26 @@ extern "C" int sdsm_minsetcover(int n, int words, const uint64_t *footprints, co
     return SDSM_OK;
 }
 
+// The same for SEVERAL independent families in one call (MinSetCover.update: one cover per touched cluster and generation -- a hundred
+// calls per image, each paying the trip through the foreign-function interface): family f has n[f] objects of words[f] uint64 each, its
+// footprints / energies / selected indices start at the running sums of n[f] * words[f] / n[f] / n[f].
+extern "C" int sdsm_minsetcover_multi(int n_families, const int32_t *n, const int32_t *words, const uint64_t *footprints, const double *energies, double beta,
+                                      int merge, int max_iter, double gamma, int32_t *selected, int32_t *n_selected)
+{
+    if (n_families < 0 || (n_families > 0 && (!n || !words || !footprints || !energies || !selected || !n_selected)) || !(beta >= 0) || !(gamma > 0 && gamma < 1)) return SDSM_ERR_ARGUMENT;
+    size_t fo = 0, eo = 0;
+    for (int f = 0; f < n_families; f++) {
+        if (n[f] < 0 || words[f] < 1) return SDSM_ERR_ARGUMENT;
+        Family F{n[f], words[f], footprints + fo, energies + eo};
+        std::vector<int> sol = n[f] > 0 ? solve_cover(F, beta, merge != 0, max_iter, gamma) : std::vector<int>();
+        n_selected[f] = (int32_t)sol.size();
+        for (size_t i = 0; i < sol.size(); i++) selected[eo + i] = sol[i];
+        fo += (size_t)n[f] * words[f];
+        eo += (size_t)n[f];
+    }
+    return SDSM_OK;
+}
+
 extern "C" int sdsm_maxsetpack(int n, int words, const uint64_t *footprints, const double *energies, int32_t *selected, int32_t *n_selected)
 {
     if (n < 0 || words < 1 || !selected || !n_selected || (n > 0 && (!footprints || !energies))) return SDSM_ERR_ARGUMENT;

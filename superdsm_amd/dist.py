@@ -86,7 +86,10 @@ def _gpu_solve_local(image, footprints, cfg, mask_info, cache=None):
     from . import _capi, engine
     batch = cache.get('batch') if cache is not None else None
     if batch is None:
-        batch = engine.Batch(image, footprints, cfg, latency_mode=True)
+        # scheduling as objects._solve: a shard that cannot fill the GPU runs in latency mode (shortest wall clock of ONE batch), a large
+        # one in throughput mode (results do not depend on the mode)
+        from .objects import LATENCY_MODE_BELOW
+        batch = engine.Batch(image, footprints, cfg, mode=1 if len(footprints) < LATENCY_MODE_BELOW else 0)
         assert np.array_equal(batch.mask_info[:len(footprints)], mask_info), 'plan of the shard disagrees with the replicated layout'
         if cache is not None:
             cache['batch'] = batch

@@ -506,7 +506,8 @@ class _LockStep:
 
     def __init__(self, n, out, stream=None):
         self.active, self.out, self.stream = n, out, stream   # stream: the torch stream this group's batches run on (None: the current one)
-        self.jobs, self.round, self.error = [], 0, None
+        self.jobs, self.round, self.error = [], 0, None      # error: a failure of the batch as a whole (every image); job_errors: of single images
+        self.job_errors = {}
         self.cv = threading.Condition()
         self.batches = 0                      # multi-image batches solved (diagnostics / tests)
 
@@ -515,9 +516,10 @@ class _LockStep:
         completes the rendezvous runs it after the batch has been launched, the others right after submitting -- so the batch
         starts as soon as the last image has its candidates, and whatever host work is left overlaps with it."""
         assert shard is None, 'process_many and sharded batches are separate ways to fill the GPUs'
+        me = threading.get_ident()
         with self.cv:
             my_round = self.round
-            self.jobs.append((list(objects), y, atoms, dsm_cfg, log_root_dir))
+            self.jobs.append((list(objects), y, atoms, dsm_cfg, log_root_dir, me))
             last = len(self.jobs) >= self.active
             if last:
                 self._flush(while_waiting)
@@ -528,6 +530,9 @@ class _LockStep:
                 self.cv.wait()
             if self.error is not None:
                 raise self.error
+            mine = self.job_errors.pop(me, None)             # a failed candidate of THIS image (CvxprogError, ...): the others go on
+            if mine is not None:
+                raise mine
 
     def leave(self):
         with self.cv:
@@ -540,12 +545,16 @@ class _LockStep:
         try:
             cfg = jobs[0][3]
             assert all(j[3] == cfg for j in jobs), 'the images of one lock-step run share the dsm/* hyper-parameters'
+            errors = [None] * len(jobs)
             if self.stream is None:
-                compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out, while_waiting=while_waiting)
+                compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out, while_waiting=while_waiting, errors=errors)
             else:
                 import torch
                 with torch.cuda.stream(self.stream):
-                    compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out, while_waiting=while_waiting)
+                    compute_objects_multi([(j[0], j[1], j[2]) for j in jobs], cfg, [j[4] for j in jobs], out=self.out, while_waiting=while_waiting, errors=errors)
+            for j, e in zip(jobs, errors):
+                if e is not None:
+                    self.job_errors[j[5]] = e
             self.batches += 1
         except BaseException as e:               # noqa: BLE001 -- handed to every waiting thread
             self.error = e
@@ -640,10 +649,19 @@ class GlobalEnergyMinimization(Stage):
             sys.setswitchinterval(interval)
             if collecting:
                 gc.enable()
-        for e in errors:
+        # an image whose candidate failed (CvxprogError) fails alone, as in the reference: the others' outputs are written, then the first
+        # failure is raised (its ``image_index`` says which image)
+        for data, prod, e in zip(datas, produced, errors):
             if e is not None:
+                continue
+            assert set(prod.keys()) == set(self.outputs), 'stage "%s" generated unexpected output' % self.name
+            for inner, outer in self.outputs.items():
+                data[outer] = prod[inner]
+        for i, e in enumerate(errors):
+            if e is not None:
+                e.image_index = i
                 raise e
-        for data, prod in zip(datas, produced):
+        for data, prod in ():
             assert set(prod.keys()) == set(self.outputs), 'stage "%s" generated unexpected output' % self.name
             for inner, outer in self.outputs.items():
                 data[outer] = prod[inner]

@@ -121,7 +121,10 @@ def solve_minsetcover_py(objects, beta, merge=True, max_iter=DEFAULT_MAX_ITER, g
 
 
 class MinSetCover:
-    """Incrementally maintained per-cluster covers (minsetcover.py:91-164)."""
+    """Incrementally maintained per-cluster covers (minsetcover.py:91-164).  The footprints of a cluster's objects are kept as bit
+    sets (appended to, never rebuilt) and the covers of ALL clusters an update touches are solved by one native call
+    (sdsm_minsetcover_multi): the stage updates the cover once per generation, which touches a dozen clusters -- a hundred solves
+    per image, each of which used to rebuild its bit sets and cross the foreign-function interface on its own."""
 
     def __init__(self, atoms, beta, adjacencies, **solve_minsetcover_kwargs):
         label_of = lambda atom: next(iter(atom.footprint))
@@ -132,21 +135,71 @@ class MinSetCover:
         self.adjacencies = adjacencies
         self.solve_minsetcover_kwargs = solve_minsetcover_kwargs
         self.objects_by_cluster = {cl: [] for cl in adjacencies.cluster_labels}
+        self._bits = {cl: ({}, [], []) for cl in adjacencies.cluster_labels}     # cluster -> (atom -> bit, footprints as ints, energies)
         for a in atoms:                                     # (one pass; the reference filters the atoms once per cluster: same lists, same order)
-            self.objects_by_cluster[adjacencies.get_cluster_label(label_of(a))].append(a)
+            self._append(adjacencies.get_cluster_label(label_of(a)), a)
         self.solution_by_cluster = {cl: self.objects_by_cluster[cl] for cl in adjacencies.cluster_labels}
+
+    def _append(self, cl, obj):
+        self.objects_by_cluster[cl].append(obj)
+        index, masks, energies = self._bits[cl]
+        m = 0
+        for a in obj.footprint:
+            i = index.get(a)
+            if i is None:
+                i = index[a] = len(index)
+            m |= 1 << i
+        masks.append(m)
+        energies.append(obj.energy)
 
     def get_atom(self, atom_label):
         return self.atoms[atom_label]
 
     def update(self, new_objects, out=None):
-        touched = set()
+        touched = []
         for obj in new_objects:
             cl = self.adjacencies.get_cluster_label(next(iter(obj.footprint)))
-            self.objects_by_cluster[cl].append(obj)
-            touched.add(cl)
-        for cl in touched:
-            self.solution_by_cluster[cl] = solve_minsetcover(self.objects_by_cluster[cl], self.beta, out=out, **self.solve_minsetcover_kwargs)
+            self._append(cl, obj)
+            if cl not in touched:
+                touched.append(cl)
+        if not touched:
+            return
+        kw = self.solve_minsetcover_kwargs
+        merge, max_iter, gamma = kw.get('merge', True), kw.get('max_iter', DEFAULT_MAX_ITER), kw.get('gamma', DEFAULT_GAMMA)
+        native = []
+        for cl in touched:                                   # objects without energies yet / non-finite ones: the Python restatement
+            e = self._bits[cl][2]
+            if all(v is not None and v == v and abs(v) != float('inf') for v in e):
+                native.append(cl)
+            else:
+                self.solution_by_cluster[cl] = solve_minsetcover(self.objects_by_cluster[cl], self.beta, out=out, **kw)
+        if not native:
+            return
+        from . import _capi
+        L = _capi.lib()
+        ns = np.array([len(self._bits[cl][1]) for cl in native], np.int32)
+        words = np.array([max(1, (len(self._bits[cl][0]) + 63) // 64) for cl in native], np.int32)
+        if int(words.max()) == 1:
+            masks = np.array([m for cl in native for m in self._bits[cl][1]], np.uint64)
+        else:
+            parts = []
+            for cl, w in zip(native, words.tolist()):
+                for m in self._bits[cl][1]:
+                    parts.extend((m >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(w))
+            masks = np.array(parts, np.uint64)
+        energies = np.array([v for cl in native for v in self._bits[cl][2]], np.float64)
+        sel = np.zeros(int(ns.sum()), np.int32)
+        nsel = np.zeros(len(native), np.int32)
+        ptr = lambda a: a.__array_interface__['data'][0]
+        code = L.sdsm_minsetcover_multi(len(native), ptr(ns), ptr(words), ptr(masks), ptr(energies), float(self.beta), int(bool(merge)), int(max_iter), float(gamma),
+                                        ptr(sel), ptr(nsel))
+        assert code == 0, 'sdsm_minsetcover_multi: bad argument'
+        pos = 0
+        sel_l, nsel_l = sel.tolist(), nsel.tolist()
+        for cl, n, k in zip(native, ns.tolist(), nsel_l):
+            objs = self.objects_by_cluster[cl]
+            self.solution_by_cluster[cl] = [objs[i] for i in sel_l[pos:pos + k]]
+            pos += n
 
     def get_cluster_costs(self, cluster_label):
         sol = self.solution_by_cluster[cluster_label]

@@ -259,11 +259,13 @@ def compute_objects(objects, y, atoms, dsm_cfg, log_root_dir, status_line=DEFAUL
     out.write(f'{status_line[1]}: {len(objects)} ({fallbacks}x fallback)')
 
 
-def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, while_waiting=None):
+def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT_COMPUTING_STATUS_LINE, out=None, while_waiting=None, errors=None):
     """:func:`compute_objects` for several images at once: ``jobs`` is a list of ``(objects, y, atoms)``, all solved as ONE
     batch of the engine (sdsm_plan_create_multi) -- the batches of a single small image (tens of candidates per generation,
     globalenergymin.py:357) cannot fill a GPU, the same generation of several images can.  Results are set in place, job by job;
-    ``cidx`` of an error counts within its job.  More than 16 images are processed in groups of 16."""
+    ``cidx`` of an error counts within its job.  More than 16 images are processed in groups of 16.  ``errors``: a list (one slot per
+    job) that receives the exception of a job whose candidate failed (CvxprogError, an implementation limit) instead of raising it for
+    the whole batch: the other images' results are complete -- the reference fails one image, not the set."""
     out = get_output(out)
     cfg = _clean_cfg(dsm_cfg)
     margin = cfg.pop('background_margin', 20)
@@ -288,7 +290,12 @@ def compute_objects_multi(jobs, dsm_cfg, log_root_dirs=None, status_line=DEFAULT
             rec, frs = records[pos:pos + len(objs)], fragments[pos:pos + len(objs)]
             if log_root_dirs is not None and log_root_dirs[j] is not None:
                 _write_logs(log_root_dirs[j], rec)
-            per_job[j] = _assign(objs, rec, frs, dt * len(objs) / len(fps))
+            try:
+                per_job[j] = _assign(objs, rec, frs, dt * len(objs) / len(fps))
+            except (CvxprogError, _capi.SdsmError) as error:
+                if errors is None:
+                    raise
+                errors[j] = error
             fb += per_job[j]
             pos += len(objs)
             total += len(objs)

@@ -354,3 +354,75 @@ def test_integral_box_slides_at_the_top_left_border():
     assert np.array_equal(got, want)
     # the unclipped-origin variant would shrink the first window to 0 rows (far row = -2 + 2 = 0)
     assert got[0, 0] == 6.0
+
+
+def test_lock_step_hands_a_failed_candidate_to_its_own_image_only(monkeypatch):
+    """GlobalEnergyMinimization.process_many solves generation k of all images as one batch; a CvxprogError of one image's candidate
+    (objects.py:309-318, 351-353) fails THAT image -- the reference fails one image, not the set -- and the other image threads go on."""
+    import threading
+    from superdsm_amd import globalenergymin as gem
+
+    def fake_multi(jobs, cfg, logs=None, status_line=None, out=None, while_waiting=None, errors=None):
+        for j, (objs, y, atoms) in enumerate(jobs):
+            for o in objs:
+                o.energy = 1.0
+            if y == 'bad':
+                errors[j] = objects.CvxprogError('convex programming failed', cidx=0)
+        return [0] * len(jobs)
+
+    monkeypatch.setattr(gem, 'compute_objects_multi', fake_multi)
+    lock = gem._LockStep(3, None)
+    res = {}
+
+    def work(name, y, rounds):
+        try:
+            for _ in range(rounds):
+                o = objects.Object()
+                o.footprint = {1}
+                lock.submit([o], y, None, {}, None)
+            res[name] = 'ok'
+        except objects.CvxprogError as e:
+            res[name] = e.cidx
+        finally:
+            lock.leave()
+
+    threads = [threading.Thread(target=work, args=('a', 'good', 3)), threading.Thread(target=work, args=('b', 'bad', 3)), threading.Thread(target=work, args=('c', 'good', 2))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=20)
+    assert res == {'a': 'ok', 'b': 0, 'c': 'ok'} and lock.batches == 3
+
+
+def test_cover_update_solves_all_touched_clusters_in_one_native_call():
+    """MinSetCover.update (minsetcover.py:142-153) through sdsm_minsetcover_multi: the same solutions as one solve_minsetcover per cluster."""
+    rng = np.random.default_rng(3)
+
+    class Adj:
+        cluster_labels = [1, 2, 3]
+
+        def get_cluster_label(self, a):
+            return 1 + (a - 1) // 5
+
+        def get_atoms_in_cluster(self, cl):
+            return set(range(5 * (cl - 1) + 1, 5 * cl + 1))
+
+    def obj(fp, e):
+        o = objects.Object()
+        o.footprint, o.energy = set(fp), float(e)
+        return o
+
+    atoms = [obj({a}, rng.uniform(20, 60)) for a in range(1, 16)]
+    cover = minsetcover.MinSetCover(atoms, 25.0, Adj())
+    for gen in range(3):
+        new = []
+        for cl in (1, 2, 3):
+            members = sorted(Adj().get_atoms_in_cluster(cl))
+            for _ in range(4):
+                k = int(rng.integers(2, 5))
+                fp = rng.choice(members, k, replace=False).tolist()
+                new.append(obj(fp, rng.uniform(15, 45) * k))
+        cover.update(new)
+        for cl in (1, 2, 3):
+            ref = minsetcover.solve_minsetcover(cover.objects_by_cluster[cl], 25.0)
+            assert [id(o) for o in cover.solution_by_cluster[cl]] == [id(o) for o in ref]
