@@ -323,7 +323,9 @@ def main():
                    'timed_seconds_total': float(sum(region_ms) * 1e-3), 'value_is': 'median over the timed regions'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
                      'traffic': measured_traffic(args.workload, n_images),
-                     'kernel': 'sdsm_k_solve (the size classes of one launch run concurrently; class 1 <128, 2560, 256 threads> does the work here)',
+                     'kernel': 'sdsm_k_solve: the size classes of one launch, which run concurrently on four queues (class 1 <128, 2560, .., 192> holds 4323 of the 4380 candidates; '
+                               'the longest chains are in classes 1b / 2b / the workgroup groups); kernel_ms = HIP events on the launch stream from the end of sdsm_k_setup to the join of the '
+                               'classes (includes sdsm_k_setup_rows of the very large regions); per-class rocprofv3 averages: profiles/r03_kernel_stats.csv',
                      'kernel_ms': kern_ms, 'setup_kernel_ms': float(np.mean(setup_ms)), 'algorithmic_bytes_per_launch': alg_bytes,
                      'achieved_in_timed_region': alg_bytes / (dt / args.steps) / 1e9,
                      'fp64_vector_tflops': flops / (kern_ms * 1e-3) / 1e12, 'fp64_vector_frac_of_78.6': flops / (kern_ms * 1e-3) / 1e12 / 78.6,
