@@ -1229,12 +1229,14 @@ __device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in,
     PROF_ADD(14, pf);
     if (failed) return failed;
     const double l2 = wave_canon_sum(n, [&](int i) { return yrow[i] * yrow[i]; });     // (the same bits for every workgroup size)
-    // back substitution L^T z = yrow: by one wavefront in registers when n <= 256 (back_substitute_wave), else blocked like the
-    // factorisation (one barrier per panel)
-    if (L::NMAX <= 128 || n <= 256) {
+    // back substitution L^T z = yrow: by one wavefront in registers when n <= 512 (back_substitute_wave; which variant depends on n
+    // alone, and all of them do the same arithmetic per row), else blocked like the factorisation (one barrier per panel: 64 us per solve
+    // of 258 unknowns against 37 us of the wavefront version at 249)
+    if (L::NMAX <= 128 || n <= 256 || (L::NMAX >= 512 && n <= 512)) {
         if (n <= 64) back_substitute_wave<1>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
         else if constexpr (L::NMAX <= 128) back_substitute_wave<2>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
-        else back_substitute_wave<4>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
+        else if (n <= 256) back_substitute_wave<4>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
+        else if constexpr (L::NMAX >= 512) back_substitute_wave<8>(Hp, yrow, dg, rbp, fstp, zl, n, tid);
         __syncthreads();
     } else {
         // back substitution L^T z = yrow, blocked the same way: the threads that have a row to update (or write the block's
@@ -1714,7 +1716,8 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int h
     // picks an instruction, the pixel passes of the other candidates of the compute unit fill the gaps (+2 % on the 8-image launch).
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x;
-    if (list >= 0) {
+    if constexpr (CLS != SDSM_CLS_1 && !WIDE) {              // (class 1 and the groups always take entry b: no second copy of the solver in their kernels)
+      if (list >= 0) {
         int *sh = reinterpret_cast<int *>(SD + L::FLAG);
         for (;;) {
             __syncthreads();                                     // (the previous candidate is finished by all threads)
@@ -1726,6 +1729,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int h
             __syncthreads();
             solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, false, CLS>(P, ci, 0, 0, false, records, masks, xi_out);
         }
+      }
     }
     int slot = blockIdx.x;
     if (WIDE) {                                              // members are claimed in start order, not by workgroup index (see wide_barrier)

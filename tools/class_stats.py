@@ -38,3 +38,7 @@ print('env percentiles', np.percentile(env, [50, 75, 90, 95, 99, 100]).astype(in
 print('slowest candidates (ms, N, M, env, evals full/value, phases A / factor / line search):')
 for k in np.argsort(-tot)[:12]:
     print('  %.2f  N=%d M=%d env=%d evals=%d/%d  A=%.2f fac=%.2f ls=%.2f' % (tot[k], N[k], recs['n_deform'][k], env[k], recs['evals_full'][k], recs['evals_value'][k], p[k, 0] / 2.4e6, p[k, 3] / 2.4e6, p[k, 4] / 2.4e6))
+print('factor_solve parts of the slowest candidates, ms: head | diag block, trailing update, barrier wait, write-back (panel loop, thread 0) | after loop | norm + back substitution')
+for k in np.argsort(-tot)[:6]:
+    print('  N=%d M=%d: %.2f | %.2f %.2f %.2f %.2f | %.2f | %.2f   (factorisations: %d)' % (N[k], recs['n_deform'][k], p[k, 13] / 2.4e6, p[k, 8] / 2.4e6, p[k, 9] / 2.4e6, p[k, 10] / 2.4e6, p[k, 11] / 2.4e6,
+                                                                                          p[k, 14] / 2.4e6, p[k, 15] / 2.4e6, recs['evals_full'][k]))
