@@ -335,7 +335,7 @@ def main():
         'status_counts': {str(k): int(v) for k, v in zip(*np.unique(recs['status'], return_counts=True))},
     }
     if rank == 0 and world == 1 and not args.no_extras:
-        out['extras'] = extras(args, scene, imgs[0], n_images)
+        out['extras'] = extras(args, scene, imgs[0], n_images, scenes)
         if not args.no_configs and args.workload == 'bbbc039_like':
             out['extras']['configs'] = other_configs(args)
     if rank == 0 and not args.no_cpu and world == 1:
@@ -357,7 +357,7 @@ def _capi_lib():
     return _capi.lib()
 
 
-def extras(args, scene, img, n_images):
+def extras(args, scene, img, n_images, scenes=None):
     """What BASELINE.json's metric names beside the solver throughput: wall clock per image through the product entry points."""
     import torch
     from superdsm_amd import config, engine, globalenergymin, image, objects
@@ -418,6 +418,18 @@ def extras(args, scene, img, n_images):
             stage.process_many(ds, cfg, out='muted')
             ts.append((time.perf_counter() - t1) * 1e3 / n_images)
         ex[f'stage_wall_ms_per_image_lockstep{n_images}'] = float(np.median(ts))
+        if scenes is not None and len({id(sc) for sc in scenes}) > 1:       # the same on the DIFFERENT images of the headline step
+            mks = lambda sc: dict(y=sc['y'], y_mask=np.ones(sc['y'].shape, bool), atoms=sc['atoms'], adjacencies=sc['adjacencies'], dsm_cfg=sc['dsm_cfg'])
+            ts, ncand = [], 0
+            for _ in range(3):
+                ds = [mks(sc) for sc in scenes]
+                gc.collect()
+                t1 = time.perf_counter()
+                stage.process_many(ds, cfg, out='muted')
+                ts.append((time.perf_counter() - t1) * 1e3 / len(scenes))
+                ncand = sum(int(d['performance'].overall_computed_object_count) for d in ds)
+            ex[f'stage_wall_ms_per_image_lockstep{len(scenes)}_different_images'] = float(np.median(ts))
+            ex['stage_candidates_of_the_different_images'] = ncand
         ex['stage_pruning'] = pruning
         ex['stage_beta'] = beta
     # (3b) the step of rounds 1-2 for comparison: ONE launch over 8 copies of this image (identical work per image, no large clusters)

@@ -75,9 +75,10 @@ _PINNED = {}                       # (device type, index, stream) -> (records st
 _PINNED_LOCK = threading.Lock()
 
 
-def fragments_from_masks(records, mask_info, mask_offset, masks, select=None):
+def fragments_from_masks(records, mask_info, mask_offset, masks, select=None, lazy=False):
     """Foreground fragments (bool arrays, views into one buffer) and offsets from downloaded records and bit-packed
-    region-bbox masks (objects.py:148-174); ``select`` (bool per candidate) skips the others (``(None, None)``)."""
+    region-bbox masks (objects.py:148-174); ``select`` (bool per candidate) skips the others (``(None, None)``).  ``lazy``: the fragment
+    as ``(buffer, start, h, w)`` -- what ``Object.fg_fragment`` turns into the array on first access."""
     L = _capi.lib()
     n = len(records)
     records = np.ascontiguousarray(records)
@@ -98,6 +99,8 @@ def fragments_from_masks(records, mask_info, mask_offset, masks, select=None):
     fw = np.where(empty, 1, records['fg_w']).tolist()
     origin = np.stack([np.where(empty, 0, records['fg_r0']), np.where(empty, 0, records['fg_c0'])], axis=1).astype(int)
     offs = off.tolist()
+    if lazy and select is None:
+        return [(o, (fb, s0, h, w)) for o, s0, h, w in zip(origin, offs, fh, fw)]
     out = []
     for i in range(n):
         if select is not None and not select[i]:
@@ -303,11 +306,11 @@ class Batch:
                             idx=idx.copy(), w=w.copy()))
         return out
 
-    def fragments(self, records, select=None, masks=None):
+    def fragments(self, records, select=None, masks=None, lazy=False):
         """Foreground fragments (bool arrays) and offsets, cropped from the bit-packed region-bbox masks."""
         if masks is None:
             masks = self.masks_dev.cpu().numpy()
-        return fragments_from_masks(records, self.mask_info, self.mask_offset, masks, select)
+        return fragments_from_masks(records, self.mask_info, self.mask_offset, masks, select, lazy)
 
 
 def algorithmic_bytes(records, mask_info):

@@ -25,6 +25,7 @@ from .pipeline import Stage
 DEFAULT_MAX_WORK_AMOUNT = 10 ** 6
 DEFAULT_SPECULATION = 3            # generations solved ahead per GPU batch (extension; 0 = the reference's batches exactly)
 DEFAULT_SPECULATION_BUDGET = 768   # ... while the batch stays within what one MI355X runs at once (256 compute units x 3 workgroups)
+DEFAULT_LOCKSTEP_BUDGET = 4096     # the same for the multi-image batches of process_many, all images together
 
 
 class PerformanceReport:
@@ -312,7 +313,7 @@ class _Speculation:
             src = self.store[k]
             if src is not o:
                 # (the fragment array is shared, not copied as Object.set would: results are replaced, never modified in place)
-                o.fg_offset, o.fg_fragment = src.fg_offset, src.fg_fragment
+                o.fg_offset, o._fg_fragment = src.fg_offset, src._fg_fragment      # (still lazy if nobody looked at it)
                 o.energy, o.on_boundary, o.is_optimal, o.processing_time = src.energy, src.on_boundary, src.is_optimal, src.processing_time
                 o.cvxprog_region_size = getattr(src, 'cvxprog_region_size', 0)
             if k in self.unasked:
@@ -588,6 +589,7 @@ class GlobalEnergyMinimization(Stage):
 
     def process(self, input_data, cfg, out, log_root_dir, solver=None, speculation_budget=DEFAULT_SPECULATION_BUDGET):
         y_img = Image.create_from_array(input_data['y'], normalize=False, mask=input_data['y_mask'])
+        y_img._sdsm_pinned = None                            # (set after the first batch: the device copy of THIS Image object serves all batches of the call)
         pruning, beta, max_iter, gamma, max_seed_distance, max_work_amount, speculation = self._hyperparameters(cfg)
         _, _, cover, objects, performance = _compute_generations(
             input_data['adjacencies'], y_img, input_data['atoms'], log_root_dir, pruning, dict(input_data['dsm_cfg']),
@@ -617,7 +619,10 @@ class GlobalEnergyMinimization(Stage):
         # -- 13.5 vs 14.2 ms per image for 8 images: a batch of 4 images takes as long as one of 8, both as long as their largest region.)
         # generations are only solved ahead while the images together leave the GPU room for it; with many images in lock step the
         # batches fill it anyway and the host logic of the image threads is what takes the time (measured: 8 images, no gain)
-        budget = DEFAULT_SPECULATION_BUDGET // len(datas) if len(datas) <= 4 else 0
+        # generations are solved ahead while the images TOGETHER stay within what the GPU takes in one go: measured on 8 different
+        # BBBC039-like images (round 3): none (12 dependent batches) 19.7 ms per image, 2048 candidates per batch 16.0, 4096 14.8 (4
+        # batches), 8192 15.1
+        budget = max(DEFAULT_SPECULATION_BUDGET, int(os.environ.get('SDSM_SPEC_BUDGET', DEFAULT_LOCKSTEP_BUDGET))) // len(datas)
         produced, errors = [None] * len(datas), [None] * len(datas)
         t0 = time.time()
 

@@ -27,7 +27,21 @@ class BaseObject:
 
     def __init__(self):
         self.fg_offset = None
-        self.fg_fragment = None
+        self._fg_fragment = None
+
+    @property
+    def fg_fragment(self):
+        """The fragment (bool array).  compute_objects stores ``(buffer, start, h, w)`` -- one unpacked byte buffer per batch -- and the
+        view is made on first access: most candidates of a generation are pruned without their mask ever being looked at."""
+        f = self._fg_fragment
+        if type(f) is tuple:
+            buf, start, h, w = f
+            f = self._fg_fragment = buf[start:start + h * w].reshape(h, w)
+        return f
+
+    @fg_fragment.setter
+    def fg_fragment(self, value):
+        self._fg_fragment = value
 
     def fill_foreground(self, out, value=True):
         assert self.fg_offset is not None and self.fg_fragment is not None
@@ -92,9 +106,11 @@ class CvxprogError(Exception):
 
 DEFAULT_COMPUTING_STATUS_LINE = ('Computing objects', 'Computed objects')
 
-# Batches of fewer candidates than this leave compute units idle even at four candidates per unit: they run in latency mode (256 threads per
-# candidate, the largest regions split over workgroup groups) also when they span several images (lock-step generations of a small image set)
-LATENCY_MODE_BELOW = 1024
+# Batches of fewer candidates than this leave most compute units idle: they run in latency mode (256 threads per candidate, regions of
+# more than 3072 pixels split over workgroup groups) also when they span several images (lock-step generations of a small image set).
+# (1024 until round 3: a lock-step batch of 588 candidates of 4 images then took 23.5 ms -- hundreds of group members, a compute unit
+# each -- against 11.6 ms in throughput mode; 8 different BBBC039-like images: 14.4-15.7 -> 13.3-14.2 ms per image with 256.)
+LATENCY_MODE_BELOW = int(os.environ.get('SDSM_LATENCY_BELOW', 256))
 
 # keys of dsm_cfg that only steer the reference's CPU implementation
 _CPU_ONLY_KEYS = ('smooth_mat_max_allocations', 'cachesize', 'cachetest', 'smooth_mat_dtype', 'cp_timeout')
@@ -112,14 +128,20 @@ def _fingerprint(a):
 def device_image(y, atoms, background_margin, refresh=False):
     """The per-image device state, cached on the ``Image`` object: y, atoms and the candidate-independent validity mask are
     uploaded / computed once, not once per candidate (objects.py:126-127 does the latter).  The cache is keyed by a content
-    fingerprint (full CRC) of ``atoms`` / ``y.model`` / ``y.mask`` and the margin; ``refresh=True`` rebuilds it unconditionally."""
+    fingerprint (full hash) of ``atoms`` / ``y.model`` / ``y.mask`` and the margin; ``refresh=True`` rebuilds it unconditionally.
+    ``y._sdsm_pinned = atoms`` (set by the stage on the Image it created itself, for the batches of one ``process`` call) skips the
+    hashing -- 0.3 ms per batch and image."""
     from . import engine
     cache = getattr(y, '_sdsm_device', None)
+    if cache is not None and not refresh and getattr(y, '_sdsm_pinned', None) is atoms and cache[0][3] == float(background_margin):
+        return cache[1]                                     # pinned by the stage for the duration of one `process` (its own Image, same atoms array)
     key = (_fingerprint(atoms), _fingerprint(y.model), None if y.mask is None else _fingerprint(y.mask), float(background_margin))
     if refresh or cache is None or cache[0] != key:
         mask = None if y.mask is None or y.mask.all() else y.mask
         cache = (key, engine.DeviceImage(y.model, mask, atoms, background_margin))
         y._sdsm_device = cache
+    if hasattr(y, '_sdsm_pinned') and y._sdsm_pinned is None:
+        y._sdsm_pinned = atoms                              # the stage opted in (GlobalEnergyMinimization.process): no hashing for the rest of the call
     return cache[1]
 
 
@@ -167,17 +189,17 @@ def _solve(images, footprints, image_of, cfg, shard, while_waiting=None):
         while_waiting()
     records, masks = batch.download()
     records = records.copy()
-    fragments = batch.fragments(records, masks=masks)
+    fragments = batch.fragments(records, masks=masks, lazy=True)
     again = np.flatnonzero(records['status'] == _capi.CAND_GIVEN_UP)
     if again.size:
         sub = engine.Batch(images if len(images) > 1 else images[0], [footprints[i] for i in again], cfg,
                            image_of=None if image_of is None else np.asarray(image_of)[again], mode=2)
         sub.launch()
         rec2, masks2 = sub.download()
-        frag2 = sub.fragments(rec2, masks=masks2)
+        frag2 = sub.fragments(rec2, masks=masks2, lazy=True)
         for j, i in enumerate(again):
             records[i] = rec2[j]
-            fragments[i] = (frag2[j][0], frag2[j][1].copy())
+            fragments[i] = frag2[j]
     return records, fragments
 
 
