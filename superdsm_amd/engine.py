@@ -246,6 +246,14 @@ class Batch:
             res.append(dict(psi=float(out[2 * i]), psi_value=float(out[2 * i + 1]), grad=out[g0:g0 + m].copy(), hess_theta=H))
         return res
 
+    def inspect_states(self):
+        """The per-candidate state words of the setup kernel (M, status, envelope size, runs) without the crops / rows of :meth:`inspect`."""
+        lay = np.zeros(16, np.int64)
+        _capi.check(_capi.lib().sdsm_plan_layout(self.plan, lay.ctypes.data_as(C.c_void_p)), 'sdsm_plan_layout')
+        ssz = int(lay[14])
+        state = self.ws[int(lay[1]):int(lay[1]) + ssz * self.n].cpu().numpy().view(np.int32).reshape(self.n, ssz // 4)
+        return [dict(M=int(r[0]), status=int(r[1]), zmax=int(r[5]), hzmax=int(r[14]), env_size=int(r[15]), NR=int(r[18])) for r in state]
+
     def inspect(self):
         """Setup-phase outputs for parity tests: per candidate (N, M, status, pixel coordinates, grid points,
         CSR-like G~ rows), reconstructed PER PIXEL from the run-packed crop (a run = the region pixels of one image row inside one
