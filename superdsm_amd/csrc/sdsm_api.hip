@@ -13,7 +13,7 @@
 #include <climits>
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
-                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev, int n_c, int n_d, int n_w);
+                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev, int n_c, int n_d, int n_w, int n_r);
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
@@ -127,6 +127,7 @@ struct sdsm_plan {
     std::vector<CandDesc> cand;
     std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those whose bound on M admits more than solve class 1, then more than class 2
     int n_order_c = 0, n_order_d = 0, n_order_w = 0;   // the last list: (candidate | member << 24) of the workgroup groups
+    int n_order_r = 0;                                  // then: (candidate | member << 24) of sdsm_k_setup_rows
     int n_setup_small = 0, n_setup_big = 0, max_label = 1;   // setup in two launches (plans that mix small and large regions): lists behind the others
     int setup_class = 2;         // LDS limits of the setup kernel that hold this plan (sdsm_setup_class)
     int mode = 0;                // sdsm_plan_set_latency_mode: 0 throughput, 1 latency, 2 no workgroup groups
@@ -235,10 +236,16 @@ static void layout_plan(sdsm_plan *p)
             if (c.N > SDSM_WIDE_MIN_PIXELS) G = std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (c.N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
             else if (latency && c.N > SDSM_WIDE_PIXELS) G = std::min<long>(SDSM_LAT_GMAX, std::max<long>(2, (c.N + SDSM_LAT_SLICE - 1) / SDSM_LAT_SLICE));   // latency mode: the largest regions of an ordinary image too
         }
-        if (G > 0) { c.wide_g = (int32_t)G; c.wide_off = p->n_wide; p->n_wide += SDSM_WIDE_SYNC + (int64_t)2 * G * SDSM_WIDE_PBUF; }
-        else { c.wide_g = 0; c.wide_off = -1; }
+        // rows of G~ by several workgroups for every large region, whether or not a workgroup group solves it (a 12 k-pixel region took a
+        // single setup workgroup 0.5-1 ms: the end of the setup kernel)
+        const long RG = c.N > SDSM_ROWS_MIN_PIXELS && n < (1 << 24) ? std::min<long>(SDSM_ROWS_MAX_G, (c.N + SDSM_ROWS_SLICE - 1) / SDSM_ROWS_SLICE) : 0;
+        c.rows_g = (int32_t)std::max<long>(RG, G > 0 ? 1 : 0);
+        c.pad1 = 0;
+        c.wide_g = (int32_t)G;
+        if (G > 0 || c.rows_g > 0) { c.wide_off = p->n_wide; p->n_wide += SDSM_WIDE_SYNC + (int64_t)2 * G * SDSM_WIDE_PBUF; }
+        else c.wide_off = -1;
     }
-    p->n_order_c = p->n_order_d = p->n_order_w = 0;
+    p->n_order_c = p->n_order_d = p->n_order_w = p->n_order_r = 0;
     p->order.resize(n);
     std::iota(p->order.begin(), p->order.end(), 0);
     std::stable_sort(p->order.begin(), p->order.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
@@ -249,6 +256,10 @@ static void layout_plan(sdsm_plan *p)
     for (int k = 0; k < n; k++) {
         const int ci = p->order[k];
         for (int g = 0; g < p->cand[ci].wide_g; g++) { p->order.push_back(ci | (g << 24)); p->n_order_w++; }
+    }
+    for (int k = 0; k < n; k++) {
+        const int ci = p->order[k];
+        for (int g = 0; g < p->cand[ci].rows_g; g++) { p->order.push_back(ci | (g << 24)); p->n_order_r++; }
     }
     // Setup: a plan whose largest region needs the large tables of the setup kernel (1024 threads per candidate) but whose candidates are
     // mostly small (an image set with a few big clusters) sets the small ones up with the 256-thread class in a launch of its own
@@ -344,7 +355,7 @@ extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, con
             r0 = std::min(r0, st[1]); r1 = std::max(r1, st[2]); c0 = std::min(c0, st[3]); c1 = std::max(c1, st[4]);
         }
         if (r1 < 0) { r0 = c0 = 0; r1 = c1 = 0; N = 0; }
-        c.image = im; c.pad1 = 0;
+        c.image = im; c.pad1 = 0; c.rows_g = 0;
         c.N = (int32_t)N; c.r0 = r0; c.c0 = c0; c.h = r1 - r0 + 1; c.w = c1 - c0 + 1;
         c.fp_off = offsets[i]; c.fp_len = offsets[i + 1] - offsets[i];
         long mc = p->no_deform ? 1 : (long)((c.h + s - 1) / s) * ((c.w + s - 1) / s);
@@ -526,7 +537,7 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
     if ((e = hipMemsetAsync((uint8_t *)d_ws + p->off_ticket, 0, 256, s)) != hipSuccess) return hipfail(e, "hipMemsetAsync");   // ticket, work-list counters
     {
         const int32_t *lists = P.order + p->n + p->n_order_c + p->n_order_d;
-        if ((e = sdsm_launch_setup(P, s, lists, p->n_order_w, p->setup_class, lists + p->n_order_w, p->n_setup_small, lists + p->n_order_w + p->n_setup_small, p->n_setup_big)) != hipSuccess)
+        if ((e = sdsm_launch_setup(P, s, lists, p->n_order_w, p->setup_class, lists + p->n_order_w + p->n_order_r, p->n_setup_small, lists + p->n_order_w + p->n_order_r + p->n_setup_small, p->n_setup_big)) != hipSuccess)
             return hipfail(e, "launch setup");
     }
     if (g_timing && (e = hipEventRecord(g_ev[1], s)) != hipSuccess) return hipfail(e, "hipEventRecord");
@@ -536,7 +547,7 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
         if ((e = acquire_sides(p)) != hipSuccess) return hipfail(e, "side streams");
         s1 = p->sides->side[0]; s2 = p->sides->side[1]; s3 = p->sides->side[2]; fj = p->sides->fj;
     }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, s3, fj, p->n_order_c, p->n_order_d, p->n_order_w)) != hipSuccess) return hipfail(e, "launch solve");
+    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, s3, fj, p->n_order_c, p->n_order_d, p->n_order_w, p->n_order_r)) != hipSuccess) return hipfail(e, "launch solve");
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }

@@ -50,6 +50,13 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #ifndef SDSM_PANEL
 #define SDSM_PANEL 4               // columns per panel (8 measured slower: 195 k vs 200 k solves/s); of the envelope Cholesky; first stored columns are multiples of it
 #endif
+#ifndef SDSM_ROWS_MIN_PIXELS
+#define SDSM_ROWS_MIN_PIXELS 4096    // larger regions: rows of G~ by several workgroups (sdsm_k_setup_rows), one per SDSM_ROWS_SLICE pixels, at most SDSM_ROWS_MAX_G
+#endif
+#ifndef SDSM_ROWS_SLICE
+#define SDSM_ROWS_SLICE 1536
+#endif
+#define SDSM_ROWS_MAX_G 48
 #define SDSM_SETUP_SMALL_PIXELS 4096   // two-launch setup: regions of at most this many pixels (that fit its tables) are set up by the 256-thread class
 #define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the largest solve class (Hessian + factor in global memory)
 
@@ -76,11 +83,12 @@ struct CandDesc {
     uint32_t perm_inv;  // crop position of the pixel with raster rank i is (i * perm_inv) mod N (low-discrepancy scatter)
     int32_t wide_g;     // > 0: solved by a group of this many workgroups (regions of more than SDSM_WIDE_MIN_PIXELS pixels)
     int64_t hglob_off;  // first double of its block in the global Hessian pool (a dense triangle of 6 + min(Mcap, 1018) unknowns; only if 6 + Mcap > SDSM_ENV_DENSE_N: the envelope may not fit LDS), else -1
-    int64_t wide_off;   // first double of the group's block in the wide pool: SDSM_WIDE_SYNC + 2 * wide_g * SDSM_WIDE_PBUF doubles; else -1
+    int64_t wide_off;   // first double of the candidate's block in the wide pool: SDSM_WIDE_SYNC (counters of the group / of sdsm_k_setup_rows) + 2 * wide_g * SDSM_WIDE_PBUF doubles; -1 if neither wide_g nor rows_g
     int32_t image;      // index into BatchParams.img (plans over several images, sdsm_plan_create_multi)
     int32_t NRcap;      // upper bound of the number of runs (min(N, rows * 4-column cells of the bounding box))
     int64_t run_off;    // first run of the candidate's packed crop (crop_y: 4 doubles per run; crop_rc, run_meta, run_q0, run_aux: one word per run)
-    int64_t pad1;
+    int32_t rows_g;     // > 0: its rows of G~ are built by this many workgroups of sdsm_k_setup_rows (regions of more than SDSM_ROWS_MIN_PIXELS pixels); sync words at wide_off
+    int32_t pad1;
 };
 
 // Written by the setup kernel.

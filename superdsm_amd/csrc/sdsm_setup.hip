@@ -308,7 +308,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     const uint8_t *__restrict__ valid = im.valid;
 
     if (blockIdx.x == 0 && tid == 0) *P.wide_ticket = 0;
-    if (cd.wide_g > 0 && tid < 2 * SDSM_WIDE_SYNC) reinterpret_cast<int *>(P.wide_pool + cd.wide_off)[tid] = 0;   // counters of the workgroup group
+    if (cd.rows_g > 0 && tid < 2 * SDSM_WIDE_SYNC) reinterpret_cast<int *>(P.wide_pool + cd.wide_off)[tid] = 0;   // counters of sdsm_k_setup_rows and of the workgroup group
     if (cd.h > T::DIM || cd.w > T::DIM || cd.N <= 0) {
         if (tid == 0) { CandState s = {}; s.status = cd.N <= 0 ? ST_ERROR : ST_UNSUPPORTED; *st = s; }
         return;
@@ -659,9 +659,9 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     const int zmax = -block_min_i32<T::WG / 64>(-cntmax, scr32);
     s.M = M; s.zmax = zmax; s.hzmax = 0;
     __syncthreads();
-    if (cd.wide_g > 0) {
-        // a very large region: its rows are built by the members of its workgroup group (sdsm_k_setup_rows), which also
-        // finish the envelope; env_size == -1 marks the state as pending
+    if (cd.rows_g > 0) {
+        // a large region: its rows are built by several workgroups (sdsm_k_setup_rows), the last of which also finishes the envelope;
+        // env_size == -1 marks the state as pending
         for (int j = tid; j < M; j += T::WG) P.env_fst[cd.xi_off + j] = j;
         s.env_size = -1; s.status = ST_OK;
         if (tid == 0) *st = s;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
     const CandDesc cd = P.cand[ci];
     CandState *st = &P.state[ci];
     if (st->status != ST_OK || st->env_size != -1) return;       // nothing pending (trivial, no G~, unsupported, ...)
-    const int M = st->M, hc = st->hc, R = P.R, G = cd.wide_g, NR = st->NR;
+    const int M = st->M, hc = st->hc, R = P.R, G = cd.rows_g, NR = st->NR;
     const uint32_t B = scatter_mult((uint32_t)(NR > 0 ? NR : 1));
     int *sync = reinterpret_cast<int *>(P.wide_pool + cd.wide_off);   // [2] ticket, [3] error flag (zeroed by sdsm_k_setup)
     for (int j = tid; j < M; j += SDSM_WG) { gridkeys[j] = P.grid_rc[cd.xi_off + j]; efirst[j] = j; }

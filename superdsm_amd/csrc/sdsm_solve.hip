@@ -141,7 +141,7 @@ __device__ __forceinline__ CandDesc uniform_desc(const CandDesc &d)
     u.N = uni(d.N); u.r0 = uni(d.r0); u.c0 = uni(d.c0); u.h = uni(d.h); u.w = uni(d.w); u.fp_off = uni(d.fp_off); u.fp_len = uni(d.fp_len);
     u.Mcap = uni(d.Mcap); u.perm_inv = uni(d.perm_inv); u.wide_g = uni(d.wide_g);
     u.hglob_off = uni((long long)d.hglob_off); u.wide_off = uni((long long)d.wide_off); u.image = uni(d.image); u.NRcap = uni(d.NRcap);
-    u.run_off = uni((long long)d.run_off); u.pad1 = 0;
+    u.run_off = uni((long long)d.run_off); u.rows_g = uni(d.rows_g); u.pad1 = 0;
     return u;
 }
 __device__ __forceinline__ CandState uniform_state(const CandState &d)
@@ -1914,7 +1914,7 @@ __global__ void sdsm_k_head_start(long long ticks)
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
                                         hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */,
-                                        int n_c, int n_d, int n_w)
+                                        int n_c, int n_d, int n_w, int n_r)
 {
     hipError_t e;
     // P.order = [all n, largest first | n_c candidates whose bound Mcap admits more than class 1 | the n_d that admit more than class 2 |
@@ -1929,7 +1929,7 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     // rows of G~ of the very large regions (one workgroup per member of their workgroup groups), on the caller's stream right behind the
     // setup kernel: a region whose envelope turns out too large for a group belongs to class 2b or the global-memory class, whose kernels
     // therefore wait for them too
-    if (n_w > 0 && (e = sdsm_launch_setup_rows(P, stream, Pw.order, n_w)) != hipSuccess) return e;
+    if (n_r > 0 && (e = sdsm_launch_setup_rows(P, stream, Pw.order + n_w, n_r)) != hipSuccess) return e;
     // fork: the side streams wait for everything queued on the caller's stream so far (setup kernels)
     if (n_c > 0 || n_d > 0 || n_w > 0) { if ((e = hipEventRecord(ev[0], stream)) != hipSuccess) return e; }
     // Queues (kernels of one stream run one after the other; the longest chains first on each):
