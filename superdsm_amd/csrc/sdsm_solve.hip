@@ -28,6 +28,7 @@
 //   One line-search sweep evaluates psi(x + t d) for 4 step lengths in a single pass (S is linear in t).
 #include "sdsm_common.h"
 #include <climits>
+#include <type_traits>
 
 extern __shared__ __align__(16) unsigned char sdsm_smem[];
 
@@ -956,43 +957,74 @@ __device__ __forceinline__ void back_substitute_wave(const double *Hp, const dou
             dgv[k] = in ? dg[i] : 0.0; yv[k] = in ? yrow[i] * dgv[k] : 0.0; rbv[k] = in ? rbp[i] : 0; fsv[k] = in ? fstp[i] : 0;
         }
         double buf[BS_DEPTH][KY], msk[BS_DEPTH][KY];          // raw row entries; the lane's reciprocal pivot where the row has an entry, else 0
-        auto fetch = [&](int j, double (&r)[KY], double (&m)[KY]) {           // row j of the factor, columns fst[j] .. j - 1 (0 elsewhere)
-            const int kj = j >> 6, lj = j & 63;
-            int rbs = rbv[0], fss = fsv[0];
+        // The rows are walked in BLOCKS of 64 (block KB: rows 64 KB .. 64 KB + 63 live in register KB): inside a block the register of
+        // row j and the registers its entries can touch (0 .. KB) are known at compile time -- no selects, and on average half of the
+        // loads and multiply-adds of a version that treats every row as if it reached every register (n = 293: 58 -> 27 us per solve).
+        auto fetch = [&](auto KBc, int j, double (&r)[KY], double (&m)[KY]) {     // row j of block KB: columns fst[j] .. j - 1 (0 elsewhere)
+            constexpr int KB = decltype(KBc)::value;
+            const int lj = j & 63;
+            const int rb = __builtin_amdgcn_readlane(rbv[KB], lj), f = __builtin_amdgcn_readlane(fsv[KB], lj);
 #pragma unroll
-            for (int k = 1; k < KY; k++) { rbs = k == kj ? rbv[k] : rbs; fss = k == kj ? fsv[k] : fss; }
-            const int rb = __builtin_amdgcn_readlane(rbs, lj), f = __builtin_amdgcn_readlane(fss, lj);
-#pragma unroll
-            for (int k = 0; k < KY; k++) {
+            for (int k = 0; k <= KB; k++) {
                 const int i = tid + 64 * k;
                 const bool in = i >= f && i < j;             // (no branch around the load: every lane reads, entry (j, j) if it has none)
                 r[k] = Hp[rb + (in ? i : j)];                // used BS_DEPTH - 1 steps later: nothing here waits for it
                 m[k] = in ? dgv[k] : 0.0;
             }
         };
-        // No branch inside the loop (the compiler's wait counts for the rows in flight are exact only in straight-line code): the
-        // steps start at the next multiple of BS_DEPTH above n -- rows >= n have y~ = 0, so whatever is fetched for them is
-        // multiplied by zero -- and the rows requested beyond row 0 at the end are row 0 again.
+        auto step = [&](auto KBc, int j, const double (&r)[KY], const double (&m)[KY]) {   // eliminate column j (a row of block KB)
+            constexpr int KB = decltype(KBc)::value;
+            double sc[KB + 1];                               // the row scaled by the lanes' reciprocal pivots: before the broadcast, off the chain
+#pragma unroll
+            for (int k = 0; k <= KB; k++) sc[k] = r[k] * m[k];
+            const int lj = j & 63;
+            const double zj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(yv[KB]), lj), __builtin_amdgcn_readlane(__double2loint(yv[KB]), lj));
+#pragma unroll
+            for (int k = 0; k <= KB; k++) yv[k] = fma(-sc[k], zj, yv[k]);        // rows >= j have a zero there: they keep their solution
+        };
+        // No branch inside a group of BS_DEPTH steps (the compiler's wait counts for the rows in flight are exact only in straight-line
+        // code): the steps start at the next multiple of BS_DEPTH above n -- rows >= n have y~ = 0, so whatever is fetched for them
+        // is multiplied by zero -- and the rows requested beyond row 0 at the end are row 0 again.
+        static_assert(64 % BS_DEPTH == 0 && BS_DEPTH == 4, "groups of steps tile the blocks");
         const int jtop = ((n + BS_DEPTH - 1) / BS_DEPTH) * BS_DEPTH - 1;
+        const int kt = jtop >> 6;
+        auto block = [&](auto KBc) {
+            constexpr int KB = decltype(KBc)::value;
+            constexpr int KP = KB > 0 ? KB - 1 : 0;          // the block below (block 0: row 0 again)
+            std::integral_constant<int, KP> KPc;
+            if (KB > kt) return;
+            const int jhi = KB == kt ? jtop : 64 * KB + 63;
+            if (KB == kt) {
 #pragma unroll
-        for (int s2 = 0; s2 < BS_DEPTH - 1; s2++) fetch(jtop - s2, buf[s2], msk[s2]);
-        for (int jb = jtop; jb >= 0; jb -= BS_DEPTH) {
-#pragma unroll
-            for (int s2 = 0; s2 < BS_DEPTH; s2++) {
-                const int j = jb - s2, jf = j - (BS_DEPTH - 1);
-                fetch(jf > 0 ? jf : 0, buf[(s2 + BS_DEPTH - 1) % BS_DEPTH], msk[(s2 + BS_DEPTH - 1) % BS_DEPTH]);
-                const int kj = j >> 6, lj = j & 63;
-                double sc[KY];                               // the row scaled by the lanes' reciprocal pivots: before the broadcast, off the chain
-#pragma unroll
-                for (int k = 0; k < KY; k++) sc[k] = buf[s2][k] * msk[s2][k];
-                double zc = yv[0];
-#pragma unroll
-                for (int k = 1; k < KY; k++) zc = k == kj ? yv[k] : zc;
-                const double zj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zc), lj), __builtin_amdgcn_readlane(__double2loint(zc), lj));
-#pragma unroll
-                for (int k = 0; k < KY; k++) yv[k] = fma(-sc[k], zj, yv[k]);    // rows >= j have a zero there: they keep their solution
+                for (int s2 = 0; s2 < BS_DEPTH - 1; s2++) fetch(KBc, jtop - s2, buf[s2], msk[s2]);
             }
-        }
+            for (int jb = jhi; jb >= 64 * KB + 2 * BS_DEPTH - 1; jb -= BS_DEPTH) {
+#pragma unroll
+                for (int s2 = 0; s2 < BS_DEPTH; s2++) {
+                    fetch(KBc, jb - s2 - (BS_DEPTH - 1), buf[(s2 + BS_DEPTH - 1) % BS_DEPTH], msk[(s2 + BS_DEPTH - 1) % BS_DEPTH]);
+                    step(KBc, jb - s2, buf[s2], msk[s2]);
+                }
+            }
+            {                                                // the last group of the block: the rows requested from its second step on are in the block below
+                const int jb = 64 * KB + BS_DEPTH - 1;
+                fetch(KBc, jb - (BS_DEPTH - 1), buf[BS_DEPTH - 1], msk[BS_DEPTH - 1]);
+                step(KBc, jb, buf[0], msk[0]);
+#pragma unroll
+                for (int s2 = 1; s2 < BS_DEPTH; s2++) {
+                    const int jf = jb - s2 - (BS_DEPTH - 1);
+                    fetch(KPc, KB > 0 ? jf : 0, buf[(s2 + BS_DEPTH - 1) % BS_DEPTH], msk[(s2 + BS_DEPTH - 1) % BS_DEPTH]);
+                    step(KBc, jb - s2, buf[s2], msk[s2]);
+                }
+            }
+        };
+        if constexpr (KY > 7) block(std::integral_constant<int, 7>{});
+        if constexpr (KY > 6) block(std::integral_constant<int, 6>{});
+        if constexpr (KY > 5) block(std::integral_constant<int, 5>{});
+        if constexpr (KY > 4) block(std::integral_constant<int, 4>{});
+        if constexpr (KY > 3) block(std::integral_constant<int, 3>{});
+        if constexpr (KY > 2) block(std::integral_constant<int, 2>{});
+        if constexpr (KY > 1) block(std::integral_constant<int, 1>{});
+        block(std::integral_constant<int, 0>{});
 #pragma unroll
         for (int k = 0; k < KY; k++) { const int i = tid + 64 * k; if (i < n) zl[i] = yv[k]; }
     }
@@ -1909,7 +1941,7 @@ __global__ void sdsm_k_head_start(long long ticks)
 // workgroup needs a whole free compute unit and waits for one while class 1 floods the chip: no more of them than the class can use.
 #define SDSM_RESIDENT_2 256         // class 2: one per compute unit (synthetic 4096^2: hundreds of candidates)
 #define SDSM_RESIDENT_2B 128        // class 2b (synthetic 4096^2: 91 candidates)
-#define SDSM_RESIDENT_3 32          // global-memory class (31 there; usually none)
+#define SDSM_RESIDENT_3 64          // global-memory class (34 there, 23-33 ms each: none may wait for another; usually none at all)
 #define SDSM_RESIDENT_1B 512        // class 1b: two per compute unit
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
