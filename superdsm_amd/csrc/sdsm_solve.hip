@@ -1149,10 +1149,23 @@ __device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in,
     bool ok = true, nonfinite = false;
     int failed = 0;
     PROF_ADD(13, pf);
+    // (the panel's row bases and last coupled row are requested one panel ahead and made uniform when the panel starts: two dependent
+    // LDS round trips less at the top of the chain)
+    int re_nx = rendp[0], rba_nx[NB];
+#pragma unroll
+    for (int a2 = 0; a2 < NB; a2++) rba_nx[a2] = rbp[a2 < n ? a2 : 0];
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = n - j0 < NB ? n - j0 : NB;
         const int jn = j0 + nb;
-        const int re = j0 < M ? uni(rendp[j0 >> NBSH]) : M - 1;      // uniform: keep the panel's index arithmetic scalar
+        const int re = j0 < M ? uni(re_nx) : M - 1;                  // uniform: keep the panel's index arithmetic scalar
+        int rba_cur[NB];
+#pragma unroll
+        for (int a2 = 0; a2 < NB; a2++) rba_cur[a2] = uni(rba_nx[a2]);
+        if (jn < n) {
+            re_nx = rendp[jn < M ? jn >> NBSH : 0];
+#pragma unroll
+            for (int a2 = 0; a2 < NB; a2++) rba_nx[a2] = rbp[jn + a2 < n ? jn + a2 : jn];
+        }
         const int nxi = jn < M && re >= jn ? re - jn + 1 : 0;
         const int th0 = jn > M ? jn : M;
         const int na = nxi + (n - th0) + 1;
@@ -1161,7 +1174,7 @@ __device__ __forceinline__ int factor_solve(const Cand &c, int M, double tau_in,
         // A. diagonal block (all rows of the panel store column j0: fst is a multiple of the panel width)
 #pragma unroll
         for (int a2 = 0; a2 < NB; a2++) {
-            const int rba = a2 < nb ? uni(rbp[j0 + a2]) : 0;
+            const int rba = a2 < nb ? rba_cur[a2] : 0;
 #pragma unroll
             for (int b2 = 0; b2 <= a2; b2++) t[a2][b2] = a2 < nb ? Hp[rba + j0 + b2] : (a2 == b2 ? 1.0 : 0.0);
         }
