@@ -201,6 +201,9 @@ static uint32_t perm_inverse(uint32_t N)
 #ifndef SDSM_LAT_GMAX
 #define SDSM_LAT_GMAX 4
 #endif
+#ifndef SDSM_WIDE_FILL
+#define SDSM_WIDE_FILL 640              // throughput mode: groups only for regions of more than (pixels of all candidates) / SDSM_WIDE_FILL pixels
+#endif
 #ifndef SDSM_WIDE_MAX_MEMBERS
 #define SDSM_WIDE_MAX_MEMBERS 256    // throughput mode: group members of one launch (= compute units of an MI355X); the largest regions first
 #endif
@@ -219,7 +222,14 @@ static void layout_plan(sdsm_plan *p)
     std::vector<char> grouped(n, 1);
     if (groups && !latency) {
         std::vector<int> big;
-        for (int i = 0; i < n; i++) if (p->cand[i].N > SDSM_WIDE_MIN_PIXELS) big.push_back(i);
+        // ... and only regions whose chain (~ its pixels) is long next to the time the whole plan keeps the chip busy (~ all pixels / compute units):
+        // the synthetic 4096^2 plan (10 073 candidates, 50 M pixels) gets no groups at all -- its 31 k-pixel regions end long before the rest does,
+        // and groups there cost compute units that the other candidates wait for (75 -> 97 ms with groups for everything above 12 288 pixels)
+        long long all_pixels = 0;
+        for (int i = 0; i < n; i++) all_pixels += p->cand[i].N;
+        const long long min_pixels = std::max<long long>(SDSM_WIDE_MIN_PIXELS, all_pixels / SDSM_WIDE_FILL);
+        for (int i = 0; i < n; i++) if (p->cand[i].N > min_pixels) big.push_back(i);
+        for (int i = 0; i < n; i++) if (p->cand[i].N <= min_pixels) grouped[i] = 0;
         std::stable_sort(big.begin(), big.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
         long members = 0;
         int cutoff = 0;                                  // regions of at most this many pixels get no group (equal regions are treated alike)

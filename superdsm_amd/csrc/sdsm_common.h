@@ -32,12 +32,16 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_K2B_EMAX 15300        //   holds a larger envelope instead (~ 160 KB): keeps most of what class 2 cannot hold out of the global-memory class
 // Very large regions are solved by a GROUP of workgroups (2 .. 8, one per 8192 pixels): each takes a slice of the pixels in
 // every pass and the partial sums / gradient / Hessian are all-reduced through global memory (sdsm_solve.hip, WIDE).
+#ifndef SDSM_WIDE_MIN_PIXELS
 #define SDSM_WIDE_MIN_PIXELS 12288
+#endif
+#ifndef SDSM_WIDE_SLICE
 #define SDSM_WIDE_SLICE 8192
+#endif
 #define SDSM_WIDE_MAX_G 8
 #define SDSM_WIDE_SYNC 16           // doubles reserved for the group's counters at the start of its pool block
 #define SDSM_WIDE_FCAP 4104         // of them for the psi-type sums of the member's super-chunks (1 count + 4 * 1024 + pad: slices of up to 2 M pixels)
-#define SDSM_WIDE_PBUF (SDSM_K2_EMAX + SDSM_MAX_N_SOLVE + 64 + SDSM_WIDE_FCAP)   // doubles one workgroup publishes per exchange
+#define SDSM_WIDE_PBUF (SDSM_K2B_EMAX + SDSM_MAX_N_SOLVE + 64 + SDSM_WIDE_FCAP)   // doubles one workgroup publishes per exchange (the larger envelope of the two group layouts: class 2 / class 2b)
 #define SDSM_WIDE_PIXELS 3072       // latency mode: larger regions go to class 2 (512 threads per candidate; a batch is as slow as its slowest candidate)
 #define SDSM_K2_EMAX 11000         // solve class 2: 6 + M <= SDSM_MAX_N_SOLVE and envelope <= 11000 doubles (LDS ~ 159 KB)
 #define SDSM_K1_DENSE_N 70         // 6 + M <= 70: even a dense triangle fits class 1
@@ -162,7 +166,7 @@ struct BatchParams {
     int32_t *env_rb;
     const float *psf;
     double *wide_pool;                 // sync words and all-reduce buffers of the workgroup groups (CandDesc.wide_off)
-    int32_t *wide_ticket;              // [0]: next entry of the group launch list (members are claimed in the order in which workgroups START, see sdsm_solve.hip)
+    int32_t *wide_ticket;              // [0] / [1] (the groups of class-2 / class-2b layout): next entry of the group launch list (members are claimed in the order in which workgroups START, see sdsm_solve.hip)
     long long wide_timeout;            // ticks of the 100 MHz wall clock a group member waits for its partners before the group is given up
     int32_t *cls_count;                // [l]: next entry of launch list l that a resident workgroup of a class beyond 1 takes (sdsm_k_solve; zeroed before every launch)
     double *hglob;                     // Hessian pool of the global-memory class (envelope too large for LDS), CandDesc.hglob_off
@@ -172,7 +176,7 @@ struct BatchParams {
 
 // Solve class of a candidate once its setup is complete: the FIRST class whose limits (6 + M <= NMAX, Hessian envelope <= EMAX
 // doubles, region <= k1_pixmax pixels for the 256-thread classes) it meets.  Results do not depend on the class.
-enum { SDSM_CLS_NONE = -1, SDSM_CLS_1 = 0, SDSM_CLS_1B = 1, SDSM_CLS_2 = 2, SDSM_CLS_2B = 3, SDSM_CLS_3 = 4, SDSM_CLS_WIDE = 5 };
+enum { SDSM_CLS_NONE = -1, SDSM_CLS_1 = 0, SDSM_CLS_1B = 1, SDSM_CLS_2 = 2, SDSM_CLS_2B = 3, SDSM_CLS_3 = 4, SDSM_CLS_WIDE = 5, SDSM_CLS_WIDE2B = 6 };
 __host__ __device__ __forceinline__ int sdsm_solve_class(int status, int M, int env_size, int N, int wide_g, int k1_pixmax)
 {
     if (status != ST_OK) return SDSM_CLS_NONE;
@@ -180,6 +184,7 @@ __host__ __device__ __forceinline__ int sdsm_solve_class(int status, int M, int 
     if (6 + Mfull > SDSM_MAX_N_SOLVE) Mfull = 0;                             // elliptical result only (flagged unsupported)
     const int nfull = 6 + Mfull, efull = Mfull > 0 ? env_size : 21;
     if (wide_g > 0 && nfull <= SDSM_MAX_N_SOLVE && efull <= SDSM_K2_EMAX) return SDSM_CLS_WIDE;
+    if (wide_g > 0 && nfull <= SDSM_K2B_NMAX && efull <= SDSM_K2B_EMAX) return SDSM_CLS_WIDE2B;      // groups with the LDS layout of class 2b
     if (nfull <= SDSM_K1_NMAX && efull <= SDSM_K1_EMAX && N <= k1_pixmax) return SDSM_CLS_1;
     if (nfull <= SDSM_K1B_NMAX && efull <= SDSM_K1B_EMAX && N <= k1_pixmax) return SDSM_CLS_1B;
     if (nfull <= SDSM_MAX_N_SOLVE && efull <= SDSM_K2_EMAX) return SDSM_CLS_2;

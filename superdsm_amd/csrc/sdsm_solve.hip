@@ -1840,14 +1840,14 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int h
     int slot = blockIdx.x;
     if (WIDE) {                                              // members are claimed in start order, not by workgroup index (see wide_barrier)
         int *tk = reinterpret_cast<int *>(SD + L::FLAG);
-        if (tid == 0) *tk = __hip_atomic_fetch_add(P.wide_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *tk = __hip_atomic_fetch_add(P.wide_ticket + (CLS == SDSM_CLS_WIDE2B ? 1 : 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         slot = uni(*tk);
         __syncthreads();
         if (slot >= P.n) return;                             // cannot happen: one ticket per workgroup of the launch
     }
     const int entry = uni(P.order[slot]);
-    solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, WIDE, WIDE ? SDSM_CLS_WIDE : CLS>(P, WIDE ? entry & 0xffffff : entry, WIDE ? (entry >> 24) & 0xff : 0, handles_rest, false, records, masks, xi_out);
+    solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, WIDE, CLS>(P, WIDE ? entry & 0xffffff : entry, WIDE ? (entry >> 24) & 0xff : 0, handles_rest, false, records, masks, xi_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2045,10 +2045,12 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     //   caller's stream: class 1 (all candidates in the host's order, largest first; the others leave at once).
     // The driver maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with another stream in use by the caller a side
     // stream may share a queue and wait behind its neighbour -- superdsm_amd sets the variable to 8 when it is imported first.
-    if (n_d > 0) {
+    if (n_d > 0 || n_w > 0) {
         if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(Pd, g_3, 3, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        // (the groups whose envelope needs the layout of class 2b: few and short next to the global-memory class behind them)
+        if (n_w > 0 && (e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, true, SDSM_CLS_WIDE2B>(Pw, n_w, -1, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if (n_d > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(Pd, g_3, 3, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if (n_d > 0 && (e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
     }
     if (n_w > 0 || n_c > 0) {
@@ -2078,7 +2080,7 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
     if (e != hipSuccess) return e;
     // join
-    if (n_d > 0 && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
+    if ((n_d > 0 || n_w > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
     if ((n_w > 0 || n_c > 0) && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
     if (n_c > 0 && (e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
     return hipSuccess;
