@@ -1240,6 +1240,46 @@ def test_given_up_workgroup_group_is_solved_again_without_groups(gpu):
     assert (batch.records()['status'] == _capi.CAND_OPTIMAL).all()
 
 
+def test_groups_of_both_lds_layouts_give_the_bytes_of_single_workgroups(gpu):
+    """The largest candidates of two BBBC039-like images with 14-17 k-pixel clusters: in throughput mode (mode 0) the regions above
+    12 288 pixels are solved by workgroup groups -- with the LDS layout of class 2 when the Hessian envelope has at most 11 000 doubles,
+    with that of class 2b (up to 15 300) otherwise -- in mode 2 by single workgroups; latency mode (1) groups the mid-size regions too.
+    The records are the same 128 bytes, and they match the CPU oracle."""
+    from oracle import oracle
+    from superdsm_amd import engine, testing
+    fps, image_of, scenes = [], [], []
+    for k, layout in enumerate((1, 2)):
+        sc = testing.make_scene('bbbc039_like', layout_index=layout)
+        cnt = np.bincount(sc['atoms'].ravel())
+        big = sorted(sc['footprints'], key=lambda fp: -sum(cnt[a] for a in fp))[:14]
+        scenes.append(dict(sc, footprints=big))
+        fps += big
+        image_of += [k] * len(big)
+    cfg = scenes[0]['dsm_cfg']
+    imgs = [engine.DeviceImage(sc['y'], None, sc['atoms'], cfg['background_margin']) for sc in scenes]
+    recs = {}
+    for mode in (0, 1, 2):
+        b = engine.Batch(imgs, fps, cfg, image_of=image_of, mode=mode)
+        b.launch()
+        gpu.cuda.synchronize()
+        recs[mode] = b.records().copy()
+        if mode == 0:
+            env = np.array([st['env_size'] for st in b.inspect_states()])
+    N = recs[0]['n_pixels']
+    grouped = N > 12288
+    assert (grouped & (env <= 11000)).any() and (grouped & (env > 11000) & (env <= 15300)).any(), 'the sample must hold groups of both layouts'
+    assert (recs[0]['status'] == 0).all()
+    for mode in (1, 2):
+        assert recs[mode].tobytes() == recs[0].tobytes(), mode
+    k0 = 0
+    for sc in scenes:
+        orecs, _, _ = oracle.compute_objects(sc['y'], None, sc['atoms'], sc['footprints'], sc['dsm_cfg'], nthreads=0)
+        r = recs[0][k0:k0 + len(sc['footprints'])]
+        assert (r['status'] == orecs['status']).all()
+        assert (np.abs(r['energy'] - orecs['energy']) <= 1e-6 * orecs['N'] / 1000 + 1e-5 * np.abs(orecs['energy'])).all()
+        k0 += len(sc['footprints'])
+
+
 def test_launch_refuses_a_workspace_uploaded_before_a_layout_change(gpu, tmp_path):
     """sdsm_plan_set_latency_mode changes the launch lists that sdsm_batch_upload put on the device: a launch with the stale
     tables is an argument error, not undefined behaviour.  Also: per-candidate log files of compute_objects."""
