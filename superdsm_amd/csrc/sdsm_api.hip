@@ -201,8 +201,11 @@ static uint32_t perm_inverse(uint32_t N)
 #ifndef SDSM_LAT_GMAX
 #define SDSM_LAT_GMAX 4
 #endif
+#ifndef SDSM_WIDE_TP_MIN_PIXELS
+#define SDSM_WIDE_TP_MIN_PIXELS 8192   // throughput mode: no groups below this many pixels
+#endif
 #ifndef SDSM_WIDE_FILL
-#define SDSM_WIDE_FILL 640              // throughput mode: groups only for regions of more than (pixels of all candidates) / SDSM_WIDE_FILL pixels
+#define SDSM_WIDE_FILL 1024              // throughput mode: groups only for regions of more than (pixels of all candidates) / SDSM_WIDE_FILL pixels
 #endif
 #ifndef SDSM_WIDE_MAX_MEMBERS
 #define SDSM_WIDE_MAX_MEMBERS 256    // throughput mode: group members of one launch (= compute units of an MI355X); the largest regions first
@@ -220,6 +223,7 @@ static void layout_plan(sdsm_plan *p)
     // chip; very large regions beyond that (synthetic 4096^2 image: 434 of them, 1296 members -- they waited for each other behind the
     // small classes) are solved as ordinary class-2 candidates, one workgroup each.
     std::vector<char> grouped(n, 1);
+    long long wide_thr = SDSM_WIDE_MIN_PIXELS;       // regions with more pixels get a group (throughput mode: set below)
     if (groups && !latency) {
         std::vector<int> big;
         // ... and only regions whose chain (~ its pixels) is long next to the time the whole plan keeps the chip busy (~ all pixels / compute units):
@@ -227,7 +231,8 @@ static void layout_plan(sdsm_plan *p)
         // and groups there cost compute units that the other candidates wait for (75 -> 97 ms with groups for everything above 12 288 pixels)
         long long all_pixels = 0;
         for (int i = 0; i < n; i++) all_pixels += p->cand[i].N;
-        const long long min_pixels = std::max<long long>(SDSM_WIDE_MIN_PIXELS, all_pixels / SDSM_WIDE_FILL);
+        const long long min_pixels = std::max<long long>(SDSM_WIDE_TP_MIN_PIXELS, all_pixels / SDSM_WIDE_FILL);
+        wide_thr = min_pixels;
         for (int i = 0; i < n; i++) if (p->cand[i].N > min_pixels) big.push_back(i);
         for (int i = 0; i < n; i++) if (p->cand[i].N <= min_pixels) grouped[i] = 0;
         std::stable_sort(big.begin(), big.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
@@ -243,7 +248,7 @@ static void layout_plan(sdsm_plan *p)
         CandDesc &c = p->cand[i];
         long G = 0;
         if (groups && grouped[i] && n < (1 << 24)) {
-            if (c.N > SDSM_WIDE_MIN_PIXELS) G = std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (c.N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
+            if (c.N > wide_thr) G = std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (c.N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
             else if (latency && c.N > SDSM_WIDE_PIXELS) G = std::min<long>(SDSM_LAT_GMAX, std::max<long>(2, (c.N + SDSM_LAT_SLICE - 1) / SDSM_LAT_SLICE));   // latency mode: the largest regions of an ordinary image too
         }
         // rows of G~ by several workgroups for every large region, whether or not a workgroup group solves it (a 12 k-pixel region took a
