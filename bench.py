@@ -323,9 +323,10 @@ def main():
                    'timed_seconds_total': float(sum(region_ms) * 1e-3), 'value_is': 'median over the timed regions'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
                      'traffic': measured_traffic(args.workload, n_images),
-                     'kernel': 'sdsm_k_solve: the size classes of one launch, which run concurrently on four queues (class 1 <128, 2560, .., 192> holds 4323 of the 4380 candidates; '
-                               'the longest chains are in classes 1b / 2b / the workgroup groups); kernel_ms = HIP events on the launch stream from the end of sdsm_k_setup to the join of the '
-                               'classes (includes sdsm_k_setup_rows of the very large regions); per-class rocprofv3 averages: profiles/r03_kernel_stats.csv',
+                     'kernel': 'sdsm_k_solve: the size classes of one launch, which run concurrently on four queues (class 1 <128, 2560, .., 192> holds '
+                               f'{int(((recs["n_deform"] + 6 <= 128)).sum())} of the {len(recs)} candidates; the longest chains are the workgroup groups of the 10-17 k-pixel clusters and class 1b); '
+                               'kernel_ms = HIP events on the launch stream from the end of sdsm_k_setup to the join of the classes (includes sdsm_k_setup_rows, the rows of G~ of the '
+                               'regions above 4096 pixels); per-class rocprofv3 averages: profiles/r03_kernel_stats.csv',
                      'kernel_ms': kern_ms, 'setup_kernel_ms': float(np.mean(setup_ms)), 'algorithmic_bytes_per_launch': alg_bytes,
                      'achieved_in_timed_region': alg_bytes / (dt / args.steps) / 1e9,
                      'fp64_vector_tflops': flops / (kern_ms * 1e-3) / 1e12, 'fp64_vector_frac_of_78.6': flops / (kern_ms * 1e-3) / 1e12 / 78.6,
@@ -455,7 +456,7 @@ def extras(args, scene, img, n_images, scenes=None):
         alg8 = engine.algorithmic_bytes(r8, b8.mask_info)
         ex['step_of_rounds_1_2_eight_copies_of_one_image'] = dict(candidates=len(r8), ms_per_step=ms, candidate_solves_per_s=len(r8) / (ms * 1e-3), solve_kernels_ms=float(np.mean(km)),
                                                                   roofline_frac=alg8 / (float(np.mean(km)) * 1e-3) / 8e12, algorithmic_bytes_per_launch=alg8,
-                                                                  note='round 2 reported 639 k solves/s, 5.06 ms solve kernel, 5.8 % on this step')
+                                                                  note='round 2 reported 639 k solves/s, 5.06 ms solve kernel, 5.8 % on this step (the headline step of rounds 1-2)')
     # (4) preprocessing: 16 B / pixel algorithmic (read g, write y)
     rng = np.random.default_rng(0)
     pre = {}

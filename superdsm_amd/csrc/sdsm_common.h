@@ -60,7 +60,9 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #ifndef SDSM_ROWS_SLICE
 #define SDSM_ROWS_SLICE 1536
 #endif
+#ifndef SDSM_ROWS_MAX_G
 #define SDSM_ROWS_MAX_G 48
+#endif
 #define SDSM_SETUP_SMALL_PIXELS 4096   // two-launch setup: regions of at most this many pixels (that fit its tables) are set up by the 256-thread class
 #define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the largest solve class (Hessian + factor in global memory)
 
