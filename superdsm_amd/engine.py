@@ -5,6 +5,7 @@ to libsdsm_hip.so.  Nothing here computes on the CPU: if the HIP library or a GP
 fails loudly.
 """
 import ctypes as C
+import itertools
 import threading
 
 import numpy as np
@@ -75,16 +76,37 @@ _PINNED = {}                       # (device type, index, stream) -> (records st
 _PINNED_LOCK = threading.Lock()
 
 
+class PackedFragments:
+    """The bit-packed region-bbox masks of one batch, kept on the host: fragment ``i`` is unpacked when somebody looks at it
+    (``Object.fg_fragment``) -- most candidates of a generation are pruned by their energy alone."""
+
+    def __init__(self, records, mask_info, mask_offset, masks):
+        self.records, self.mask_info, self.mask_offset, self.masks = records, mask_info, mask_offset, masks
+
+    def get(self, i):
+        return fragments_from_masks(self.records[i:i + 1], self.mask_info[i:i + 1], self.mask_offset[i:i + 1], self.masks)[0][1]
+
+
+def _empty_fragment(records):
+    return (records['fg_h'] <= 0) | np.isin(records['status'], (_capi.CAND_TRIVIAL, _capi.CAND_ERROR, _capi.CAND_GIVEN_UP))
+
+
 def fragments_from_masks(records, mask_info, mask_offset, masks, select=None, lazy=False):
     """Foreground fragments (bool arrays, views into one buffer) and offsets from downloaded records and bit-packed
     region-bbox masks (objects.py:148-174); ``select`` (bool per candidate) skips the others (``(None, None)``).  ``lazy``: the fragment
-    as ``(buffer, start, h, w)`` -- what ``Object.fg_fragment`` turns into the array on first access."""
+    as ``(PackedFragments, index)`` -- what ``Object.fg_fragment`` turns into the array on first access; ``masks`` is copied (it may be
+    a view of a staging buffer)."""
     L = _capi.lib()
     n = len(records)
     records = np.ascontiguousarray(records)
     mask_info = np.ascontiguousarray(mask_info[:n], np.int32)
     mask_offset = np.ascontiguousarray(mask_offset[:n], np.int64)
     masks = np.ascontiguousarray(masks, np.uint8)
+    if lazy and select is None:
+        empty = _empty_fragment(records)
+        origin = np.stack([np.where(empty, 0, records['fg_r0']), np.where(empty, 0, records['fg_c0'])], axis=1).astype(int)
+        src = PackedFragments(records.copy(), mask_info.copy(), mask_offset.copy(), masks.copy())      # (the inputs may be views of staging buffers)
+        return [(o, (src, i)) for i, o in enumerate(origin)]
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)
     off = np.zeros(n + 1, np.int64)
     total = L.sdsm_unpack_fragments(ptr(records), ptr(mask_info), ptr(mask_offset), ptr(masks), n, None, ptr(off))
@@ -94,13 +116,11 @@ def fragments_from_masks(records, mask_info, mask_offset, masks, select=None, la
     L.sdsm_unpack_fragments(ptr(records), ptr(mask_info), ptr(mask_offset), ptr(masks), n, ptr(buf), ptr(off))
     off[n] = total
     fb = buf.view(bool)
-    empty = (records['fg_h'] <= 0) | np.isin(records['status'], (_capi.CAND_TRIVIAL, _capi.CAND_ERROR, _capi.CAND_GIVEN_UP))
+    empty = _empty_fragment(records)
     fh = np.where(empty, 1, records['fg_h']).tolist()
     fw = np.where(empty, 1, records['fg_w']).tolist()
     origin = np.stack([np.where(empty, 0, records['fg_r0']), np.where(empty, 0, records['fg_c0'])], axis=1).astype(int)
     offs = off.tolist()
-    if lazy and select is None:
-        return [(o, (fb, s0, h, w)) for o, s0, h, w in zip(origin, offs, fh, fw)]
     out = []
     for i in range(n):
         if select is not None and not select[i]:
@@ -116,8 +136,8 @@ def plan_mask_boxes(image, footprints, dsm_cfg):
     L = _capi.lib()
     n = len(footprints)
     offs = np.zeros(n + 1, np.int32)
-    np.cumsum(np.fromiter((len(fp) for fp in footprints), np.int64, n), out=offs[1:])
-    labels = np.fromiter((int(a) for fp in footprints for a in fp), np.int32, int(offs[-1]))
+    np.cumsum(np.fromiter(map(len, footprints), np.int64, n), out=offs[1:])
+    labels = np.fromiter(itertools.chain.from_iterable(footprints), np.int32, int(offs[-1]))
     cfg = _capi.make_config(dict(dsm_cfg, background_margin=image.background_margin))
     stats = np.ascontiguousarray(image.atom_stats, np.int32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -142,10 +162,10 @@ class Batch:
         self.image = self.images[0]
         assert 1 <= len(self.images) <= 16, 'a plan covers 1 .. 16 images'
         self.n = len(footprints)
-        lens = np.fromiter((len(fp) for fp in footprints), np.int64, self.n)
+        lens = np.fromiter(map(len, footprints), np.int64, self.n)
         offs = np.zeros(self.n + 1, np.int32)
         np.cumsum(lens, out=offs[1:])
-        labels = np.fromiter((int(a) for fp in footprints for a in fp), np.int32, int(offs[-1]))
+        labels = np.fromiter(itertools.chain.from_iterable(footprints), np.int32, int(offs[-1]))
         self.image_of = None if image_of is None else np.ascontiguousarray(image_of, np.int32)
         assert len(self.images) == 1 or (self.image_of is not None and len(self.image_of) == self.n)
         margins = {im.background_margin for im in self.images}

@@ -31,12 +31,12 @@ class BaseObject:
 
     @property
     def fg_fragment(self):
-        """The fragment (bool array).  compute_objects stores ``(buffer, start, h, w)`` -- one unpacked byte buffer per batch -- and the
-        view is made on first access: most candidates of a generation are pruned without their mask ever being looked at."""
+        """The fragment (bool array).  compute_objects stores ``(engine.PackedFragments, index)`` -- the bit-packed masks of the batch --
+        and the fragment is unpacked on first access: most candidates of a generation are pruned without their mask ever being looked at."""
         f = self._fg_fragment
         if type(f) is tuple:
-            buf, start, h, w = f
-            f = self._fg_fragment = buf[start:start + h * w].reshape(h, w)
+            src, i = f
+            f = self._fg_fragment = src.get(i)
         return f
 
     @fg_fragment.setter
