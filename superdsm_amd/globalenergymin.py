@@ -23,8 +23,9 @@ from .output import Text, get_output
 from .pipeline import Stage
 
 DEFAULT_MAX_WORK_AMOUNT = 10 ** 6
-DEFAULT_SPECULATION = 3            # generations solved ahead per GPU batch (extension; 0 = the reference's batches exactly)
-DEFAULT_SPECULATION_BUDGET = 768   # ... while the batch stays within what one MI355X runs at once (256 compute units x 3 workgroups)
+DEFAULT_SPECULATION = 8            # generations solved ahead per GPU batch (extension; 0 = the reference's batches exactly)
+DEFAULT_SPECULATION_BUDGET = 2048  # ... while the batch stays within this many candidates (measured, BBBC039-like images, depth / budget: 3 / 768 = 2-3 batches
+                                   # per image, 9.7 / 17.2 / 35.3 ms on three layouts; 8 / 2048 = 1-2 batches, 9.1 / 14.5 / 32.8 ms; candidates solved in vain: the same 32-120)
 DEFAULT_LOCKSTEP_BUDGET = 4096     # the same for the multi-image batches of process_many, all images together
 
 
