@@ -183,7 +183,7 @@ def _solve(images, footprints, image_of, cfg, shard, while_waiting=None):
         assert len(images) == 1, 'sharded batches cover one image'
         return shard.solve(images[0], footprints, cfg)
     batch = engine.Batch(images if len(images) > 1 else images[0], footprints, cfg, image_of=image_of,
-                         mode=1 if len(images) == 1 or len(footprints) < LATENCY_MODE_BELOW else 0)   # a batch that cannot fill the GPU: shortest wall clock
+                         mode=1 if len(footprints) < LATENCY_MODE_BELOW else 0)   # a batch that cannot fill the GPU: shortest wall clock
     batch.launch()
     if while_waiting is not None:                          # host work of the caller while the kernels run (the launch is asynchronous)
         while_waiting()

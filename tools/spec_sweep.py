@@ -5,10 +5,10 @@ from superdsm_amd import globalenergymin, testing
 from superdsm_amd.output import get_output
 out = get_output('muted')
 stage = globalenergymin.GlobalEnergyMinimization()
-for layout in (0, 2):
+for layout in (0, 2, 5):
     s = testing.make_scene('bbbc039_like', max_size=3, layout_index=layout)
     mk = lambda: dict(y=s['y'], y_mask=np.ones(s['y'].shape, bool), atoms=s['atoms'], adjacencies=s['adjacencies'], dsm_cfg=s['dsm_cfg'])
-    for depth, budget in ((0, 768), (3, 768), (8, 2048)):
+    for depth, budget in ((8, 2048),):
         cfg = {'beta': 150.0, 'pruning': os.environ.get('PRUNING', 'isbi24'), 'speculation': depth}
         for _ in range(3): r = stage.process(mk(), cfg, out, None, speculation_budget=budget)
         ts = []
