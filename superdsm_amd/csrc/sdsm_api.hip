@@ -222,35 +222,39 @@ static void layout_plan(sdsm_plan *p)
     // members are resident.  In throughput mode the LARGEST regions get groups until their members add up to the compute units of the
     // chip; very large regions beyond that (synthetic 4096^2 image: 434 of them, 1296 members -- they waited for each other behind the
     // small classes) are solved as ordinary class-2 candidates, one workgroup each.
-    std::vector<char> grouped(n, 1);
-    long long wide_thr = SDSM_WIDE_MIN_PIXELS;       // regions with more pixels get a group (throughput mode: set below)
+    long long wide_thr = SDSM_WIDE_MIN_PIXELS;       // regions with more pixels get a group of one member per SDSM_WIDE_SLICE pixels (throughput mode: set below)
     if (groups && !latency) {
-        std::vector<int> big;
         // ... and only regions whose chain (~ its pixels) is long next to the time the whole plan keeps the chip busy (~ all pixels / compute units):
         // the synthetic 4096^2 plan (10 073 candidates, 50 M pixels) gets no groups at all -- its 31 k-pixel regions end long before the rest does,
         // and groups there cost compute units that the other candidates wait for (75 -> 97 ms with groups for everything above 12 288 pixels)
         long long all_pixels = 0;
         for (int i = 0; i < n; i++) all_pixels += p->cand[i].N;
-        const long long min_pixels = std::max<long long>(SDSM_WIDE_TP_MIN_PIXELS, all_pixels / SDSM_WIDE_FILL);
-        wide_thr = min_pixels;
-        for (int i = 0; i < n; i++) if (p->cand[i].N > min_pixels) big.push_back(i);
-        for (int i = 0; i < n; i++) if (p->cand[i].N <= min_pixels) grouped[i] = 0;
+        wide_thr = std::max<long long>(SDSM_WIDE_TP_MIN_PIXELS, all_pixels / SDSM_WIDE_FILL);
+    }
+    auto group_size = [&](long N) -> long {              // members of the group a region of N pixels would get (0: none)
+        if (!groups || n >= (1 << 24)) return 0;
+        if (N > wide_thr) return std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
+        if (latency && N > SDSM_WIDE_PIXELS) return std::min<long>(SDSM_LAT_GMAX, std::max<long>(2, (N + SDSM_LAT_SLICE - 1) / SDSM_LAT_SLICE));   // latency mode: the largest regions of an ordinary image too
+        return 0;
+    };
+    // the member budget (both modes: a single image with many large clusters -- 636 candidates, 16 k-pixel regions -- asked for several hundred
+    // members in latency mode and took 15 ms instead of 12)
+    std::vector<char> grouped(n, 1);
+    {
+        std::vector<int> big;
+        for (int i = 0; i < n; i++) if (group_size(p->cand[i].N) > 0) big.push_back(i);
         std::stable_sort(big.begin(), big.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
         long members = 0;
         int cutoff = 0;                                  // regions of at most this many pixels get no group (equal regions are treated alike)
         for (int i : big) {
-            members += std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (p->cand[i].N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
+            members += group_size(p->cand[i].N);
             if (members > SDSM_WIDE_MAX_MEMBERS) { cutoff = p->cand[i].N; break; }
         }
         for (int i : big) if (p->cand[i].N <= cutoff) grouped[i] = 0;
     }
     for (int i = 0; i < n; i++) {
         CandDesc &c = p->cand[i];
-        long G = 0;
-        if (groups && grouped[i] && n < (1 << 24)) {
-            if (c.N > wide_thr) G = std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (c.N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
-            else if (latency && c.N > SDSM_WIDE_PIXELS) G = std::min<long>(SDSM_LAT_GMAX, std::max<long>(2, (c.N + SDSM_LAT_SLICE - 1) / SDSM_LAT_SLICE));   // latency mode: the largest regions of an ordinary image too
-        }
+        const long G = grouped[i] ? group_size(c.N) : 0;
         // rows of G~ by several workgroups for every large region, whether or not a workgroup group solves it (a 12 k-pixel region took a
         // single setup workgroup 0.5-1 ms: the end of the setup kernel)
         const long RG = c.N > SDSM_ROWS_MIN_PIXELS && n < (1 << 24) ? std::min<long>(SDSM_ROWS_MAX_G, (c.N + SDSM_ROWS_SLICE - 1) / SDSM_ROWS_SLICE) : 0;
