@@ -201,6 +201,9 @@ static uint32_t perm_inverse(uint32_t N)
 #ifndef SDSM_LAT_GMAX
 #define SDSM_LAT_GMAX 4
 #endif
+#ifndef SDSM_ROWS_MAX_REGIONS
+#define SDSM_ROWS_MAX_REGIONS 1024     // plans with more regions above SDSM_ROWS_MIN_PIXELS build all rows in the setup kernel
+#endif
 #ifndef SDSM_WIDE_TP_MIN_PIXELS
 #define SDSM_WIDE_TP_MIN_PIXELS 8192   // throughput mode: no groups below this many pixels
 #endif
@@ -252,12 +255,17 @@ static void layout_plan(sdsm_plan *p)
         }
         for (int i : big) if (p->cand[i].N <= cutoff) grouped[i] = 0;
     }
+    long rows_regions = 0;
+    for (int i = 0; i < n; i++) rows_regions += p->cand[i].N > SDSM_ROWS_MIN_PIXELS;
+    const bool rows_multi = rows_regions <= SDSM_ROWS_MAX_REGIONS;
     for (int i = 0; i < n; i++) {
         CandDesc &c = p->cand[i];
         const long G = grouped[i] ? group_size(c.N) : 0;
         // rows of G~ by several workgroups for every large region, whether or not a workgroup group solves it (a 12 k-pixel region took a
         // single setup workgroup 0.5-1 ms: the end of the setup kernel)
-        const long RG = c.N > SDSM_ROWS_MIN_PIXELS && n < (1 << 24) ? std::min<long>(SDSM_ROWS_MAX_G, (c.N + SDSM_ROWS_SLICE - 1) / SDSM_ROWS_SLICE) : 0;
+        // (only while such regions are few enough to be the END of the setup kernel: with the 5000 of the synthetic 4096^2 plan the setup kernel is
+        // busy throughout and builds the rows itself at a little more than half the cost -- 5.2 instead of 9.2 ms there)
+        const long RG = rows_multi && c.N > SDSM_ROWS_MIN_PIXELS && n < (1 << 24) ? std::min<long>(SDSM_ROWS_MAX_G, (c.N + SDSM_ROWS_SLICE - 1) / SDSM_ROWS_SLICE) : 0;
         c.rows_g = (int32_t)std::max<long>(RG, G > 0 ? 1 : 0);
         c.pad1 = 0;
         c.wide_g = (int32_t)G;
