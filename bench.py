@@ -484,7 +484,7 @@ def extras(args, scene, img, n_images, scenes=None):
     return ex
 
 
-def launch_figures(scene, n_timed=5):
+def launch_figures(scene, n_timed=15):
     """One engine launch over all candidates of one image (throughput scheduling, as the headline step): wall clock per launch, HIP-event
     time of the solve kernels, solves/s and the roofline fraction by SURVEY.md 8(d)'s byte count."""
     import torch
@@ -492,7 +492,7 @@ def launch_figures(scene, n_timed=5):
     L = _capi.lib()
     img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
     batch = engine.Batch(img, scene['footprints'], scene['dsm_cfg'])
-    for _ in range(2):
+    for _ in range(4):
         batch.launch()
     torch.cuda.synchronize()
     ts = []
