@@ -160,12 +160,13 @@ int64_t sdsm_plan_xi_count(const sdsm_plan *plan);
  * position p at element ((s / 4) * N + p) * 4 + s % 4 of the candidate's block -- and grid offset xi_offset[i]. */
 int sdsm_plan_layout(const sdsm_plan *plan, int64_t *out);
 /* Scheduling of one batch, mode =
- *   0  throughput (default): every candidate whose system fits is solved by a 256-thread workgroup, two per compute unit -- most
- *      candidate solves per second when the GPU is full (plans over several images, several batches in flight); only regions of
- *      more than 12288 pixels are solved by a GROUP of cooperating 512-thread workgroups;
- *   1  latency: regions of more than 3072 pixels are solved by groups of 2-4 workgroups too, which shortens the slowest candidates
- *      and with them the wall clock of a single batch (the reference waits for all candidates of an image before the set-cover
- *      step, globalenergymin.py:131-137);
+ *   0  throughput (default): every candidate whose system fits is solved by a 192- or 256-thread workgroup, two to four per compute
+ *      unit -- most candidate solves per second when the GPU is full (plans over several images, several batches in flight); only
+ *      regions of more than max(8192, pixels of all candidates of the plan / 1024) pixels are solved by a GROUP of cooperating
+ *      512-thread workgroups (the largest first, until the members add up to 256);
+ *   1  latency: regions of more than 3072 pixels are solved by groups of 2-4 workgroups too (same member budget), which shortens
+ *      the slowest candidates and with them the wall clock of a single batch (the reference waits for all candidates of an image
+ *      before the set-cover step, globalenergymin.py:131-137);
  *   2  no groups: every candidate by a single workgroup (slow for very large regions; the way to solve candidates again whose
  *      group was given up, SDSM_CAND_GIVEN_UP).
  * Results do not depend on the mode.  It changes the launch lists and the workspace size: call it before
