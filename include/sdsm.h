@@ -172,6 +172,10 @@ int sdsm_plan_layout(const sdsm_plan *plan, int64_t *out);
  * Results do not depend on the mode.  It changes the launch lists and the workspace size: call it before
  * sdsm_plan_workspace_bytes / sdsm_batch_upload; a launch on a workspace uploaded before the change fails with SDSM_ERR_ARGUMENT. */
 int sdsm_plan_set_latency_mode(sdsm_plan *plan, int mode);
+/* What the current mode schedules per candidate (host only, diagnostics and tests): group_members[i] = workgroups of the group that
+ * solves candidate i (0: a single workgroup), rows_workgroups[i] = workgroups that build its rows of G~ (0: the setup workgroup itself).
+ * Either pointer may be NULL. */
+int sdsm_plan_schedule(const sdsm_plan *plan, int32_t *group_members, int32_t *rows_workgroups);
 int sdsm_plan_xi_offsets(const sdsm_plan *plan, int64_t *xi_offset);
 
 /* ---- post-processing, per-object work (superdsm/postprocess.py:254-337) ------------------------------------- */

@@ -61,6 +61,7 @@ SYMBOLS = {
     'sdsm_plan_xi_count': (_i64, [_vp]),
     'sdsm_plan_xi_offsets': (_i32, [_vp, _vp]),
     'sdsm_plan_layout': (_i32, [_vp, _vp]),
+    'sdsm_plan_schedule': (_i32, [_vp, _vp, _vp]),
     'sdsm_plan_set_latency_mode': (_i32, [_vp, _i32]),
     'sdsm_post_objects': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _f64, _vp, _vp]),
     'sdsm_gaussian_workspace_bytes': (_sz, [_i32, _i32, _f64]),

@@ -452,6 +452,16 @@ extern "C" int sdsm_plan_describe(const sdsm_plan *p, int32_t *mask_info, int64_
     return SDSM_OK;
 }
 
+extern "C" int sdsm_plan_schedule(const sdsm_plan *p, int32_t *group_members, int32_t *rows_workgroups)
+{
+    if (!p) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_schedule: null plan");
+    for (int i = 0; i < p->n; i++) {
+        if (group_members) group_members[i] = p->cand[i].wide_g;
+        if (rows_workgroups) rows_workgroups[i] = p->cand[i].rows_g;
+    }
+    return SDSM_OK;
+}
+
 extern "C" int sdsm_plan_xi_offsets(const sdsm_plan *p, int64_t *xi_offset)
 {
     if (!p || !xi_offset) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_xi_offsets: null argument");

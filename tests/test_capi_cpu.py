@@ -65,6 +65,78 @@ def test_host_only_entry_points():
     assert b'alpha' in lib.sdsm_last_error()
 
 
+def _plan_of_squares(sides):
+    """A host-only plan over one candidate per atom, atoms = squares of the given side lengths on a grid (statistics only: area, extents)."""
+    from superdsm_amd import _capi
+    lib = _capi.lib()
+    n = len(sides)
+    pitch = max(sides)
+    per_row = 60000 // pitch
+    stats = np.zeros((n + 1, 6), np.int32)
+    for k, sd in enumerate(sides, start=1):
+        r, c = ((k - 1) // per_row) * pitch, ((k - 1) % per_row) * pitch
+        stats[k] = (sd * sd, r, r + sd - 1, c, c + sd - 1, 0)
+    H, W = ((n - 1) // per_row + 1) * pitch, per_row * pitch
+    assert H <= 65535
+    cfg = _capi.make_config(dict(alpha=0.033, smooth_amount=4, smooth_subsample=8, background_margin=0))
+    offs = np.arange(n + 1, dtype=np.int32)
+    labels = np.arange(1, n + 1, dtype=np.int32)
+    plan = lib.sdsm_plan_create(H, W, n, stats.ctypes.data_as(C.c_void_p), C.byref(cfg), n, offs.ctypes.data_as(C.c_void_p), labels.ctypes.data_as(C.c_void_p))
+    assert plan, lib.sdsm_last_error()
+    return plan
+
+
+def _schedule(plan, n, mode):
+    from superdsm_amd import _capi
+    lib = _capi.lib()
+    assert lib.sdsm_plan_set_latency_mode(plan, mode) == 0
+    g, r = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    assert lib.sdsm_plan_schedule(plan, g.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p)) == 0
+    return g, r
+
+
+def test_scheduling_policy_of_a_plan_is_host_logic():
+    """Workgroup groups and the workgroups that build the rows of G~ (sdsm_api.hip, layout_plan), without a GPU: groups in throughput mode
+    only for regions that are long next to the whole plan, the largest first within a budget of 256 members; latency mode groups the
+    mid-size regions too; mode 2 none; rows by several workgroups only while regions above 4096 pixels are few."""
+    from superdsm_amd import _capi
+    lib = _capi.lib()
+    # a few large regions among small ones (an image set with clusters): sides 30 (900 px) ... 180 (32 400 px)
+    sides = [30] * 200 + [70] * 20 + [100] * 6 + [180] * 2
+    n = len(sides)
+    N = np.array(sides) ** 2
+    plan = _plan_of_squares(sides)
+    npx = np.zeros(n, np.int32)
+    assert lib.sdsm_plan_describe(plan, None, None, npx.ctypes.data_as(C.c_void_p)) == 0
+    assert (npx == N).all()
+    g, r = _schedule(plan, n, 0)
+    assert ((g > 0) == (N > 8192)).all() and (g[N > 8192] >= 2).all() and g.max() <= 8         # 10 000 px: 2 members, 32 400 px: 4
+    assert ((r > 0) == (N > 4096)).all() and r[N == 4900].tolist() == [4] * 20                 # one workgroup per 1536 pixels
+    g1, _ = _schedule(plan, n, 1)
+    assert ((g1 > 0) == (N > 3072)).all() and (g1[N == 4900] == 3).all()                      # latency mode: one member per 2048 pixels, at most 4
+    g2, r2 = _schedule(plan, n, 2)
+    assert (g2 == 0).all() and ((r2 > 0) == (N > 4096)).all()
+    lib.sdsm_plan_destroy(plan)
+    # thousands of mid-size regions (the synthetic 4096^2 plan): the chip is full whatever the largest does -- no groups, rows inside the setup kernel
+    sides = [70] * 8000 + [120] * 40
+    n = len(sides)
+    plan = _plan_of_squares(sides)
+    g, r = _schedule(plan, n, 0)
+    assert (g == 0).all() and (r == 0).all()
+    lib.sdsm_plan_destroy(plan)
+    # many large regions: the member budget goes to the largest (regions of equal size are treated alike: all or none)
+    sides = list(range(120, 220)) + [100] * 100
+    n = len(sides)
+    N = np.array(sides) ** 2
+    plan = _plan_of_squares(sides)
+    for mode in (0, 1):
+        g, _ = _schedule(plan, n, mode)
+        assert 128 < g.sum() <= 256 and (g[N == 10000] == 0).all()
+        smallest_grouped = N[g > 0].min()
+        assert (g[N > smallest_grouped] > 0).all()
+    lib.sdsm_plan_destroy(plan)
+
+
 def test_compute_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
