@@ -118,7 +118,8 @@ struct PlanImage { int H, W, n_atoms; };
 // Side streams / fork-join events of the solve classes.  A plan borrows a set at its first launch and gives it back when it is
 // destroyed: creating and destroying HIP streams costs milliseconds (hipStreamDestroy synchronises), a reference-style caller
 // builds a plan per batch.  A set carries no state between users (events are recorded before they are waited for).
-struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; int device; };
+#include <mutex>
+struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; int device; std::mutex enqueue; };
 struct sdsm_plan {
     int n = 0;
     std::vector<PlanImage> images;             // one entry for sdsm_plan_create, several for sdsm_plan_create_multi
@@ -148,8 +149,13 @@ struct sdsm_plan {
 };
 
 #include <mutex>
+// ONE set of side streams per device, shared by all plans and created at the first launch that needs it: the runtime maps streams onto
+// GPU_MAX_HW_QUEUES hardware queues in the order of their creation, and a set created late (a set per live plan: the tenth stream of
+// the process and later) came to share queues with the caller's stream or within itself -- the classes of one launch then ran one after
+// the other (NIH3T3-like launch inside the full bench run 8.3 instead of 6.4 ms).  Launches enqueue under the set's mutex (fork and join
+// events belong to the set); launches from different caller streams share the side queues.
 static std::mutex g_pool_mutex;
-static std::vector<SideSet *> g_side_pool;
+static std::vector<SideSet *> g_side_sets;
 
 static hipError_t acquire_sides(const sdsm_plan *p)
 {
@@ -157,14 +163,8 @@ static hipError_t acquire_sides(const sdsm_plan *p)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        for (size_t i = 0; i < g_side_pool.size(); i++) if (g_side_pool[i]->device == dev) {
-            p->sides = g_side_pool[i];
-            g_side_pool.erase(g_side_pool.begin() + i);
-            return hipSuccess;
-        }
-    }
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (SideSet *q : g_side_sets) if (q->device == dev) { p->sides = q; return hipSuccess; }
     SideSet *s = new SideSet();
     s->device = dev;
     // high priority: the classes beyond 1 are few, long candidates (the end of a launch) whose 512-thread workgroups each need a whole
@@ -173,6 +173,7 @@ static hipError_t acquire_sides(const sdsm_plan *p)
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithPriority(&s->side[i], hipStreamNonBlocking, prio_high)) != hipSuccess) { delete s; return e; }
     for (int i = 0; i < 4; i++) if ((e = hipEventCreateWithFlags(&s->fj[i], hipEventDisableTiming)) != hipSuccess) { delete s; return e; }
+    g_side_sets.push_back(s);
     p->sides = s;
     return hipSuccess;
 }
@@ -424,11 +425,7 @@ extern "C" sdsm_plan *sdsm_plan_create(int H, int W, int n_atoms, const int32_t 
 extern "C" void sdsm_plan_destroy(sdsm_plan *plan)
 {
     if (!plan) return;
-    if (plan->sides) {                                   // back to the pool (work queued on its streams is ordered by their events)
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        g_side_pool.push_back(plan->sides);
-    }
-    delete plan;
+    delete plan;                                         // (the side streams belong to the device, not to the plan)
 }
 extern "C" int sdsm_plan_set_latency_mode(sdsm_plan *p, int on)
 {
@@ -584,7 +581,11 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
         if ((e = acquire_sides(p)) != hipSuccess) return hipfail(e, "side streams");
         s1 = p->sides->side[0]; s2 = p->sides->side[1]; s3 = p->sides->side[2]; fj = p->sides->fj;
     }
-    if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, s3, fj, p->n_order_c, p->n_order_d, p->n_order_w, p->n_order_r)) != hipSuccess) return hipfail(e, "launch solve");
+    {
+        std::unique_lock<std::mutex> enq;
+        if (p->sides) enq = std::unique_lock<std::mutex>(p->sides->enqueue);
+        if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, s3, fj, p->n_order_c, p->n_order_d, p->n_order_w, p->n_order_r)) != hipSuccess) return hipfail(e, "launch solve");
+    }
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;
 }
