@@ -167,11 +167,11 @@ static hipError_t acquire_sides(const sdsm_plan *p)
     for (SideSet *q : g_side_sets) if (q->device == dev) { p->sides = q; return hipSuccess; }
     SideSet *s = new SideSet();
     s->device = dev;
-    // high priority: the classes beyond 1 are few, long candidates (the end of a launch) whose 512-thread workgroups each need a whole
-    // compute unit; as units become free the dispatcher serves these queues before the thousands of small workgroups of class 1
-    int prio_low = 0, prio_high = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithPriority(&s->side[i], hipStreamNonBlocking, prio_high)) != hipSuccess) { delete s; return e; }
+    // Default priority.  (High priority for these queues -- the few long candidates of a launch are on them -- changes nothing where the
+    // launch is short and costs 3 ms of the 71 of the synthetic 4096^2 launch, where every class has work: measured, round 3.  A fourth
+    // side stream for class 2, beside the groups instead of behind them: 8 different BBBC039-like images 8.2 -> 8.5 ms, GOWT1-like
+    // 4.9 -> 5.2: its 256 resident workgroups take compute units from the group members at the start.)
+    for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking)) != hipSuccess) { delete s; return e; }
     for (int i = 0; i < 4; i++) if ((e = hipEventCreateWithFlags(&s->fj[i], hipEventDisableTiming)) != hipSuccess) { delete s; return e; }
     g_side_sets.push_back(s);
     p->sides = s;
