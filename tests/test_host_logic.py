@@ -42,6 +42,49 @@ def test_extract_foreground_fragment_kat():
     np.testing.assert_array_equal(frag, [[False]])
 
 
+def test_fragments_unpacked_on_demand_equal_the_batch_unpack():
+    """compute_objects keeps the bit-packed masks of a batch on the host (engine.PackedFragments) and Object.fg_fragment unpacks one
+    fragment when it is looked at: the same arrays as unpacking the whole batch (objects.py:148-174 applied to the region-bbox masks),
+    and independent of the buffers the batch was read from (staging buffers are reused by the next batch)."""
+    from superdsm_amd import _capi, engine
+    rng = np.random.default_rng(5)
+    n = 7
+    recs = np.zeros(n, _capi.RECORD_DTYPE)
+    info = np.zeros((n, 4), np.int32)
+    offs = np.zeros(n, np.int64)
+    words, expect = [], []
+    for i in range(n):
+        h, w = int(rng.integers(3, 9)), int(rng.integers(3, 40))
+        r0, c0 = int(rng.integers(0, 50)), int(rng.integers(0, 50))
+        box = rng.random((h, w)) < 0.5
+        box[0, :] = box[-1, :] = False                           # the fragment is the bounding box of the mask inside its box
+        box[1, 1] = box[h - 2, w - 2] = True
+        rr, cc = np.nonzero(box)
+        frag = box[rr.min():rr.max() + 1, cc.min():cc.max() + 1]
+        info[i] = (r0, c0, h, w)
+        offs[i] = 4 * len(words)
+        bits = np.zeros(((h * w + 31) // 32) * 32, np.uint8)
+        bits[:h * w] = box.reshape(-1)
+        words += list(np.packbits(bits.reshape(-1, 8), axis=1, bitorder='little').reshape(-1).view(np.uint32))
+        recs[i]['fg_r0'], recs[i]['fg_c0'], recs[i]['fg_h'], recs[i]['fg_w'] = r0 + rr.min(), c0 + cc.min(), frag.shape[0], frag.shape[1]
+        expect.append(((r0 + rr.min(), c0 + cc.min()), frag))
+    recs[3]['status'] = _capi.CAND_TRIVIAL                         # no foreground: [[False]] at the origin (objects.py:172-174)
+    expect[3] = ((0, 0), np.zeros((1, 1), bool))
+    masks = np.array(words, np.uint32).view(np.uint8).copy()
+    eager = engine.fragments_from_masks(recs, info, offs, masks)
+    lazy = engine.fragments_from_masks(recs, info, offs, masks, lazy=True)
+    masks[:] = 0xff                                                 # the staging buffer is reused by the next batch
+    recs['fg_h'] = 1
+    for i in range(n):
+        obj = objects.Object()
+        obj.fg_offset, obj.fg_fragment = lazy[i]
+        assert type(obj._fg_fragment) is tuple                      # still packed
+        for off, frag in (eager[i], (obj.fg_offset, obj.fg_fragment)):
+            assert tuple(int(v) for v in off) == expect[i][0]
+            np.testing.assert_array_equal(frag, expect[i][1])
+        assert isinstance(obj._fg_fragment, np.ndarray) and obj.fg_fragment is obj.fg_fragment
+
+
 # ---- reference KATs: tests/test_image.py:10-40 -------------------------------------------------------------
 def test_get_pixel_map_kat():
     expected = np.array([np.repeat(np.arange(5.0)[:, None], 5, 1), np.repeat(np.arange(5.0)[None, :], 5, 0)])
