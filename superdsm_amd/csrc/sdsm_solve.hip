@@ -2008,8 +2008,8 @@ __global__ void sdsm_k_head_start(long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 #ifndef SDSM_HEAD_START_US
-#define SDSM_HEAD_START_US 60
-#endif
+#define SDSM_HEAD_START_US 120      // (end of round 3, side streams at default priority: 20 us: 9.5 / 5.96 ms per step of 8 different images / 8 copies;
+#endif                              //  60: 8.2 / 5.63; 120: 8.2 / 5.37; 200: 8.1 / 5.45; 300: 8.2 / 5.52 -- the resident workgroups of the empty classes are gone by then)
 
 // Resident workgroups of the classes beyond 1 (each pops entries of its launch list until the list is exhausted).  A 512-thread
 // workgroup needs a whole free compute unit and waits for one while class 1 floods the chip: no more of them than the class can use.
