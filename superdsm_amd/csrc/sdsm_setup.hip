@@ -14,6 +14,16 @@
 
 namespace {
 
+// The PSF table: in LDS when it fits, else in global memory.  The two are read through pointers of their OWN address space (one uniform
+// branch): a select between a generic LDS and a generic global pointer compiles to flat loads, which wait for every global store the
+// wavefront has in flight (vmcnt(0)) -- the entries the loop has just written: 1.2 us per grid point in the rows of G~.
+typedef const float __attribute__((address_space(3))) *lds_cfloat_p;
+__device__ __forceinline__ float psf_at(const float *psf_lds, const float *psf, int pidx)
+{
+    if (psf_lds) return ((lds_cfloat_p)psf_lds)[pidx];
+    return ((g_cfloat_p)psf)[pidx];
+}
+
 struct WeightCtx {
     int cr, cc, R, k;
     const float *psf;       // global table
@@ -26,17 +36,18 @@ struct WeightCtx {
 
 __device__ __forceinline__ float wval(WeightCtx &c, int j)
 {
-    uint32_t key = c.keys[j];
-    int dr = (int)(key >> 16) - c.cr, dc = (int)(key & 0xffffu) - c.cc;
-    int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
-    if (adr <= c.R && adc <= c.R) {
-        const int pidx = (c.R + dr) * c.k + (c.R + dc);
-        float v = c.psf_lds ? c.psf_lds[pidx] : c.psf[pidx];
-        c.wmax = v > c.wmax ? v : c.wmax;
-        c.nnz++;
-        return v;
-    }
-    return 0.f;
+    // (no branch: the eight calls of a group then have their reads of the key and of the PSF table in flight together; a point outside the
+    // window reads the table's centre and contributes +0)
+    const uint32_t key = c.keys[j];
+    const int dr = (int)(key >> 16) - c.cr, dc = (int)(key & 0xffffu) - c.cc;
+    const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
+    const bool in = adr <= c.R && adc <= c.R;
+    const int pidx = in ? (c.R + dr) * c.k + (c.R + dc) : c.R * c.k + c.R;
+    const float t = psf_at(c.psf_lds, c.psf, pidx);
+    const float v = in ? t : 0.f;
+    c.wmax = v > c.wmax ? v : c.wmax;
+    c.nnz += in ? 1 : 0;
+    return v;
 }
 
 // numpy's pairwise float32 sum of one block of <= 128 elements (loops_utils.h.src).  Only the grid points j in
@@ -199,6 +210,13 @@ __device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDes
             }
         }
         if (rowbad) { bad = true; P.run_meta[cd.run_off + pos] = rp.mask << 24; continue; }
+        // The float32 quotient psf / sum, correctly rounded (the reference divides in float32, dsm.py:193), as a float64 product with the
+        // float64 reciprocal of the sum: the quotient of two 24-bit significands is either a float32 number or at least 2^-49 (relative)
+        // away from every rounding boundary of float32, and the product is off by less than 2^-52 -- the same bits as the division,
+        // without its dozen instructions and two mode switches per entry.
+        double rsumk[SDSM_RUN];
+#pragma unroll
+        for (int k = 0; k < SDSM_RUN; k++) rsumk[k] = 1.0 / (double)sumk[k];
         // pass 2: one entry per grid point inside the window of at least one pixel: the normalised weights of the four pixels and
         // the pixels for which the entry is a LEADING one (>= hess_thr * the pixel's row maximum: the solver's approximate Hessian
         // uses only those; S and the gradient use all).  Leading entries fill the slots from 0 upwards -- in ascending column
@@ -209,23 +227,32 @@ __device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDes
             const uint32_t gk = gridkeys[j];
             const int dr = (int)(gk >> 16) - cr, gc = (int)(gk & 0xffffu);
             if ((dr < 0 ? -dr : dr) > R) continue;
-            float nw[SDSM_RUN];
+            // (the four pixels side by side without branches: their reads of the PSF table and their divisions overlap; a pixel whose window does
+            // not hold the point reads the table's centre and keeps the weight 0)
+            float nw[SDSM_RUN], tv[SDSM_RUN];
+            bool ink[SDSM_RUN];
             uint32_t lead = 0;
             bool any = false;
 #pragma unroll
             for (int k = 0; k < SDSM_RUN; k++) {
                 const int dc = gc - cck[k];
-                nw[k] = 0.f;
-                if ((dc < 0 ? -dc : dc) <= R) {
-                    const int pidx = (R + dr) * P.k + (R + dc);
-                    nw[k] = __fdiv_rn(psf_lds ? psf_lds[pidx] : P.psf[pidx], sumk[k]);
-                    any = true;
-                    if (!(nw[k] < limk[k])) {
-                        lead |= 1u << k;
-                        // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
-                        if (hzk[k] == 0) mn[k] = j; else atomicMin(&efirst[j], mn[k]);
-                        hzk[k]++;
-                    }
+                ink[k] = (dc < 0 ? -dc : dc) <= R;
+                const int pidx = ink[k] ? (R + dr) * P.k + (R + dc) : R * P.k + R;
+                tv[k] = psf_at(psf_lds, P.psf, pidx);
+                any = any || ink[k];
+            }
+#pragma unroll
+            for (int k = 0; k < SDSM_RUN; k++) {
+                const float q = (float)((double)tv[k] * rsumk[k]);    // == __fdiv_rn(tv[k], sumk[k]), see rsumk
+                nw[k] = ink[k] ? q : 0.f;
+                if (ink[k] && !(nw[k] < limk[k])) lead |= 1u << k;
+            }
+#pragma unroll
+            for (int k = 0; k < SDSM_RUN; k++) {
+                if ((lead >> k) & 1u) {
+                    // grid points coupled by this pixel in the solver's Hessian: every one of them with the smallest of them
+                    if (hzk[k] == 0) mn[k] = j; else atomicMin(&efirst[j], mn[k]);
+                    hzk[k]++;
                 }
             }
             if (!any) continue;
