@@ -28,8 +28,8 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_K1_EMAX 2560
 #define SDSM_K1B_NMAX 256          // solve class 1b: 6 + M <= 256 and envelope <= 7168 doubles: 256 threads, LDS ~ 79 KB, TWO workgroups per compute unit
 #define SDSM_K1B_EMAX 7168         //   (between class 1 and class 2, whose 157 KB leave one workgroup per compute unit: regions of ~5-15 k pixels, M ~ 100-250)
-#define SDSM_K2B_NMAX 512          // solve class 2b: 6 + M <= 512 and envelope <= 15300 doubles: the LDS that class 2 spends on vectors of 1024 unknowns
-#define SDSM_K2B_EMAX 15300        //   holds a larger envelope instead (~ 160 KB): keeps most of what class 2 cannot hold out of the global-memory class
+#define SDSM_K2B_NMAX 512          // solve class 2b: 6 + M <= 512 and envelope <= 15170 doubles: the LDS that class 2 spends on vectors of 1024 unknowns
+#define SDSM_K2B_EMAX 15170        //   holds a larger envelope instead (~ 160 KB): keeps most of what class 2 cannot hold out of the global-memory class
 // Very large regions are solved by a GROUP of workgroups (2 .. 8, one per 8192 pixels): each takes a slice of the pixels in
 // every pass and the partial sums / gradient / Hessian are all-reduced through global memory (sdsm_solve.hip, WIDE).
 #ifndef SDSM_WIDE_MIN_PIXELS

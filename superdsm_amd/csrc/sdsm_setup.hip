@@ -336,7 +336,8 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
 
     if (blockIdx.x == 0 && tid == 0) *P.wide_ticket = 0;
     if (cd.rows_g > 0 && tid < 2 * SDSM_WIDE_SYNC) reinterpret_cast<int *>(P.wide_pool + cd.wide_off)[tid] = 0;   // counters of sdsm_k_setup_rows and of the workgroup group
-    if (cd.h > T::DIM || cd.w > T::DIM || cd.N <= 0) {
+    // (a G~ block of 4 GB and more: the solve kernels address a candidate's entries by 32-bit byte offsets)
+    if (cd.h > T::DIM || cd.w > T::DIM || cd.N <= 0 || (long long)cd.NRcap * P.zcap_run >= (1ll << 28)) {
         if (tid == 0) { CandState s = {}; s.status = cd.N <= 0 ? ST_ERROR : ST_UNSUPPORTED; *st = s; }
         return;
     }

@@ -27,6 +27,7 @@
 //   depend on the workgroup size, the size class, the number of workgroups that share it or anything else in its launch.
 //   One line-search sweep evaluates psi(x + t d) for 4 step lengths in a single pass (S is linear in t).
 #include "sdsm_common.h"
+#include "sdsm_logtab.h"
 #include <climits>
 #include <type_traits>
 
@@ -77,8 +78,9 @@ struct Lay {
     static constexpr int WGS = WGSIZE, NWAVES = WGSIZE / 64;
     static constexpr bool GLOBAL_H = GLOBALH;      // Hessian in global memory (envelope larger than LDS)
     static constexpr int W = NMAX + 2;             // vectors are indexed up to n (right-hand-side row) inclusive
-    static constexpr int X = 0, G = W, D = 2 * W, XT = 3 * W, SC = 4 * W, YROW = 5 * W, TMP = 6 * W;
-    static constexpr int RED = 7 * W, FLAG = RED + NWAVES * 32, MS = FLAG + 2, IB = MS + 42 * NSLOT;   // MS: fixed-point moment accumulators, 21 sums x 2 words x NSLOT lane slots
+    static constexpr int LT = 0, B0 = 2 * SDSM_LOGTAB_N;   // the table of log_w (the same address in every class), then the vectors
+    static constexpr int X = B0, G = B0 + W, D = B0 + 2 * W, XT = B0 + 3 * W, SC = B0 + 4 * W, YROW = B0 + 5 * W, TMP = B0 + 6 * W;
+    static constexpr int RED = B0 + 7 * W, FLAG = RED + NWAVES * 32, MS = FLAG + 2, IB = MS + 42 * NSLOT;   // MS: fixed-point moment accumulators, 21 sums x 2 words x NSLOT lane slots
     static constexpr int NPANEL = NMAX / SDSM_PANEL + 2;
     static constexpr int IB_DOUBLES = (2 * W + NPANEL + 1) / 2;      // int arrays: rb[W], fst[W], rend[NPANEL]
     static constexpr int HP = IB + IB_DOUBLES;
@@ -336,42 +338,43 @@ __device__ __forceinline__ double rcp_f64(double x)
     return fma(fma(-x, y, 1.0), y, y);
 }
 
-// log(w) for 1 <= w <= 2: w = 2^e m with m in (sqrt(1/2), sqrt(2)], log m = 2 atanh((m - 1) / (m + 1)), 1.3e-16 absolute
-__device__ __forceinline__ double log_1_2(double w)
+// The table of log_w at the start of dynamic LDS (once per workgroup; a barrier follows before any pass over the pixels).
+__device__ __forceinline__ void load_log_table(int tid)
 {
-    const bool big = w > 1.4142135623730951;
-    const double m = big ? 0.5 * w : w;
-    const double den = m + 1.0, num = m - 1.0;
-    const double y = rcp_f64(den);
-    double sq = num * y;
-    sq = fma(fma(-sq, den, num), y, sq);
-    const double z = sq * sq;
-    double p = 1.0 / 21.0;
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    p = fma(p, z, 1.0);
-    const double l = 2.0 * sq * p;
-    return big ? l + 0.6931471805599453 : l;
+    if (tid < SDSM_LOGTAB_N) reinterpret_cast<f64x2 *>(SD)[tid] = reinterpret_cast<const f64x2 *>(sdsm_logtab)[tid];
+    __syncthreads();
+}
+
+// log(w), w = 1 + u, 0 <= u <= 1: w = c_j (1 + s) with c_j = 1 + j / 64 the nearest table point (|s| <= 1 / 128), log w = log c_j +
+// log1p(s); the table (LDS, sdsm_logtab.h: 1 / c_j rounded and the logarithm of ITS reciprocal, so s = fma(w, 1 / c_j, -1) is exact for
+// what the table means) and a degree-7 series: 1.1e-16 absolute, 5e-16 relative (w = 1 gives 0, w = 2 the rounded ln 2).  12
+// instructions; the atanh series without a table took 40 and eleven 64-bit constants (round 4).
+__device__ __forceinline__ double log_w(double u, double w)
+{
+    const int j = (int)fma(u, 64.0, 0.5);
+    const f64x2 e = reinterpret_cast<const f64x2 *>(SD)[j];
+    const double s = fma(w, e.x, -1.0);
+    double p = 1.0 / 7.0;
+    p = fma(p, s, -1.0 / 6.0);
+    p = fma(p, s, 0.2);
+    p = fma(p, s, -0.25);
+    p = fma(p, s, 1.0 / 3.0);
+    p = fma(p, s, -0.5);
+    p = fma(p, s, 1.0);
+    return fma(s, p, e.y);
 }
 
 // log(1 + exp(-t))   (dsm.py:298-300, 319-322: log(1 + h), h = exp(-t); -t below the exp guard -- the same value)
 __device__ __forceinline__ double softplus_neg(double t)
 {
     double a = fabs(t);
-    a = a < 750.0 ? a : 750.0;
-    const double u = exp_neg(a);                         // exp(-|t|) in (0, 1]
-    const double phi = log_1_2(1.0 + u) + (t < 0 ? -t : 0.0);
-    return t != t ? t : phi;                             // NaN stays NaN
+    a = a < 750.0 ? a : 750.0;                           // (NaN -> 750)
+    const double u = exp_neg(a);                         // exp(-|t|) in [0, 1]
+    return (log_w(u, 1.0 + u) + fmax(-t, 0.0)) + t * 0.0;   // (t * 0: a non-finite t gives NaN -- every caller treats a non-finite psi as a failed evaluation)
 }
 
-// loss terms of one pixel given t = y * S     (dsm.py:298-300, 306-310, 319-322, 344, 361-366)
+// loss terms of one pixel given t = y * S     (dsm.py:298-300, 306-310, 319-322, 344, 361-366).  A non-finite t makes phi NaN
+// (the evaluation then counts as failed, whatever r and dcurv are).
 __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, double *r, double *dcurv)
 {
     const double t = yv * S;
@@ -379,17 +382,14 @@ __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, dou
     a = a < 750.0 ? a : 750.0;
     const double u = exp_neg(a);                         // exp(-|t|)
     const double w = 1.0 + u;
-    const double ph = log_1_2(w) + (t < 0 ? -t : 0.0);
+    *phi = (log_w(u, w) + fmax(-t, 0.0)) + t * 0.0;
     const double rw = rcp_f64(w);
-    double theta = t >= 0 ? u * rw : rw;                 // h / (1 + h), h = exp(-t)
-    const bool bad = t != t;
-    theta = bad ? t : theta;
-    *phi = bad ? t : ph;
+    const double q = u * rw;
+    const double theta = t >= 0 ? q : rw;                // h / (1 + h), h = exp(-t)
     *r = -yv * theta;
     // kappa = theta - theta^2 (dsm.py:361) = u / (1 + u)^2: the product form has no cancellation for theta -> 1 (the reference's
     // difference loses all digits there: kappa < 1e-16 comes out as 0 or 1.1e-16)
-    const double kap = u * rw * rw;
-    *dcurv = yv * yv * (bad ? t : kap);
+    *dcurv = (yv * yv) * (q * rw);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -464,13 +464,20 @@ __device__ __forceinline__ void run_pass(const Cand &c, double (&tot)[K], Body &
 
 // The pixels of a run: local coordinates (one row: u; consecutive columns: v[k]), intensities (0 for the absent ones), presence bits.
 struct RunPix { double u, v[SDSM_RUN], y[SDSM_RUN]; unsigned pm; int nnz, hz; };
-__device__ __forceinline__ void load_run(const Cand &c, int p, bool active, RunPix &rp)
+// Loads through a uniform base (SGPR pair) and a 32-bit byte offset per lane (the `saddr` form of the global loads: no 64-bit address
+// arithmetic in the vector ALUs).  The G~ block of a candidate is below 4 GB (sdsm_k_setup refuses larger ones).
+template <class T> __device__ __forceinline__ T gld(const T SDSM_GLOBAL *base, unsigned byte_off)
 {
-    uint32_t meta = 0, rc = 0;
-    f64x2 ya = {0, 0}, yb = {0, 0};
-    if (active) { meta = c.meta[p]; rc = c.crop_rc[p]; ya = c.crop_y2[2 * (size_t)p]; yb = c.crop_y2[2 * (size_t)p + 1]; }
-    rp.y[0] = ya.x; rp.y[1] = ya.y; rp.y[2] = yb.x; rp.y[3] = yb.y;
-    rp.pm = meta >> 24; rp.nnz = (int)(meta & 0xfffu); rp.hz = (int)((meta >> 12) & 0xfffu);
+    return *reinterpret_cast<const T SDSM_GLOBAL *>(reinterpret_cast<const char SDSM_GLOBAL *>(base) + byte_off);
+}
+// A lane beyond the slice reads the slice's last run (no branch around the loads) and treats it as empty: no pixels, no entries, y = 0.
+__device__ __forceinline__ int load_pos(const Cand &c, int p, bool active) { return active ? p : c.p_hi - 1; }
+__device__ __forceinline__ void load_run(const Cand &c, int pl, bool active, RunPix &rp)
+{
+    const uint32_t meta = gld(c.meta, (unsigned)pl * 4u), rc = gld(c.crop_rc, (unsigned)pl * 4u);
+    const f64x2 ya = gld(c.crop_y2, (unsigned)pl * 32u), yb = gld(c.crop_y2, (unsigned)pl * 32u + 16u);
+    rp.y[0] = active ? ya.x : 0.0; rp.y[1] = active ? ya.y : 0.0; rp.y[2] = active ? yb.x : 0.0; rp.y[3] = active ? yb.y : 0.0;
+    rp.pm = active ? meta >> 24 : 0u; rp.nnz = active ? (int)(meta & 0xfffu) : 0; rp.hz = active ? (int)((meta >> 12) & 0xfffu) : 0;
     rp.u = ((double)(rc >> 16) - c.rmid) * c.inv_hr;
     const int col0 = (int)(rc & 0xffffu);
 #pragma unroll
@@ -486,18 +493,33 @@ __device__ __forceinline__ void poly_surface(const RunPix &rp, const double *xv,
 // entries the rows of the chunk of position p are padded to (uniform: one scalar load per wavefront and chunk)
 __device__ __forceinline__ int chunk_entries(const Cand &c, int pb) { return (int)c.aux[pb >> 6]; }
 
-// S += G~ xi for the four pixels of run p: the entries are requested EBATCH at a time (all loads of a batch before the first use)
-template <int STRIDE>
-__device__ __forceinline__ void smooth_add(const Cand &c, const double *xv, int p, bool active, int kh, double (&S)[SDSM_RUN])
+// The entries of a run, EBATCH at a time: entry j of run position pl is element j * NR + pl of the candidate's block -- byte offsets
+// (32 bits) that advance by NR elements per entry.  kh is uniform (the chunk's padded entry count): the tests on it are scalar branches.
+struct EntryCursor { unsigned ow, oi, sw, si; };
+__device__ __forceinline__ EntryCursor entry_cursor(const Cand &c, int pl)
 {
+    EntryCursor e; e.ow = (unsigned)pl * 16u; e.oi = (unsigned)pl * 4u; e.sw = (unsigned)c.NR * 16u; e.si = (unsigned)c.NR * 4u;
+    return e;
+}
+__device__ __forceinline__ void load_entries(const Cand &c, EntryCursor &e, int j0, int kh, f32x4 (&w)[EBATCH], uint32_t (&im)[EBATCH])
+{
+#pragma unroll
+    for (int t = 0; t < EBATCH; t++) {
+        w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
+        if (j0 + t < kh) { w[t] = gld(c.ell_w4, e.ow + (unsigned)t * e.sw); im[t] = gld(c.ell_im, e.oi + (unsigned)t * e.si); }
+    }
+    e.ow += EBATCH * e.sw; e.oi += EBATCH * e.si;
+}
+
+// S += G~ xi for the four pixels of the run at position pl: all loads of a batch before the first use
+template <int STRIDE>
+__device__ __forceinline__ void smooth_add(const Cand &c, const double *xv, int pl, int kh, double (&S)[SDSM_RUN])
+{
+    EntryCursor ec = entry_cursor(c, pl);
     for (int j0 = 0; j0 < kh; j0 += EBATCH) {
         f32x4 w[EBATCH];
         uint32_t im[EBATCH];
-#pragma unroll
-        for (int t = 0; t < EBATCH; t++) {
-            w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
-            if (j0 + t < kh && active) { w[t] = c.ell_w4[(size_t)(j0 + t) * c.NR + p]; im[t] = c.ell_im[(size_t)(j0 + t) * c.NR + p]; }
-        }
+        load_entries(c, ec, j0, kh, w, im);
 #pragma unroll
         for (int t = 0; t < EBATCH; t++) {
             if (j0 + t < kh) {
@@ -509,16 +531,13 @@ __device__ __forceinline__ void smooth_add(const Cand &c, const double *xv, int 
 }
 
 // The same for S(x) and S(d) at once: xd holds the pairs (x_j, d_j), one 16-byte LDS read per entry
-__device__ __forceinline__ void smooth_add2(const Cand &c, const double *xd, int p, bool active, int kh, double (&S0)[SDSM_RUN], double (&Sd)[SDSM_RUN])
+__device__ __forceinline__ void smooth_add2(const Cand &c, const double *xd, int pl, int kh, double (&S0)[SDSM_RUN], double (&Sd)[SDSM_RUN])
 {
+    EntryCursor ec = entry_cursor(c, pl);
     for (int j0 = 0; j0 < kh; j0 += EBATCH) {
         f32x4 w[EBATCH];
         uint32_t im[EBATCH];
-#pragma unroll
-        for (int t = 0; t < EBATCH; t++) {
-            w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
-            if (j0 + t < kh && active) { w[t] = c.ell_w4[(size_t)(j0 + t) * c.NR + p]; im[t] = c.ell_im[(size_t)(j0 + t) * c.NR + p]; }
-        }
+        load_entries(c, ec, j0, kh, w, im);
 #pragma unroll
         for (int t = 0; t < EBATCH; t++) {
             if (j0 + t < kh) {
@@ -540,10 +559,11 @@ __device__ __forceinline__ double eval_value(const Cand &c, int xo, int M)
     double tot[1];
     run_pass<L, 1>(c, tot, [&](int p, bool active, double (&v)[1]) {
         RunPix rp;
-        load_run(c, p, active, rp);
+        const int pl = load_pos(c, p, active);
+        load_run(c, pl, active, rp);
         double S[SDSM_RUN];
         poly_surface(rp, xv, S);
-        if (M > 0) smooth_add<1>(c, xv, p, active, chunk_entries(c, __builtin_amdgcn_readfirstlane(p)), S);
+        if (M > 0) smooth_add<1>(c, xv, pl, chunk_entries(c, __builtin_amdgcn_readfirstlane(p)), S);
         double ps = 0;
 #pragma unroll
         for (int k = 0; k < SDSM_RUN; k++) if ((rp.pm >> k) & 1u) ps += softplus_neg(rp.y[k] * S[k]);
@@ -574,7 +594,8 @@ __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, doubl
     double ps[LS_K];
     run_pass<L, LS_K>(c, ps, [&](int p, bool active, double (&v)[LS_K]) {
         RunPix rp;
-        load_run(c, p, active, rp);
+        const int pl = load_pos(c, p, active);
+        load_run(c, pl, active, rp);
         double S0[SDSM_RUN], Sd[SDSM_RUN];
         {
             const double uu = rp.u * rp.u, u2 = 2 * rp.u;
@@ -587,7 +608,7 @@ __device__ __forceinline__ void eval_line(const Cand &c, int M, double t0, doubl
                 Sd[k] = vv * xd[3] + rp.v[k] * b1 + a1;
             }
         }
-        if (M > 0) smooth_add2(c, xd, p, active, chunk_entries(c, __builtin_amdgcn_readfirstlane(p)), S0, Sd);
+        if (M > 0) smooth_add2(c, xd, pl, chunk_entries(c, __builtin_amdgcn_readfirstlane(p)), S0, Sd);
 #pragma unroll
         for (int k2 = 0; k2 < LS_K; k2++) v[k2] = 0;
 #pragma unroll
@@ -759,11 +780,12 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
     double tot[1];
     run_pass<L, 1>(c, tot, [&](int p, bool active, double (&pv)[1]) {
         RunPix rp;
-        load_run(c, p, active, rp);
+        const int pl = load_pos(c, p, active);
+        load_run(c, pl, active, rp);
         const int kh = M > 0 ? chunk_entries(c, __builtin_amdgcn_readfirstlane(p)) : 0;
         double S[SDSM_RUN];
         poly_surface(rp, xv, S);
-        if (M > 0) smooth_add<1>(c, xv, p, active, kh, S);
+        if (M > 0) smooth_add<1>(c, xv, pl, kh, S);
         double r[SDSM_RUN], d[SDSM_RUN], psum = 0;
 #pragma unroll
         for (int k = 0; k < SDSM_RUN; k++) {
@@ -805,8 +827,9 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
         uint32_t lim[HZREG];
 #pragma unroll
         for (int a = 0; a < HZREG; a++) { lw[a].x = 0.f; lw[a].y = 0.f; lw[a].z = 0.f; lw[a].w = 0.f; lim[a] = 0; }
-        int p2 = p;
+        int p2 = pl;
         asm volatile("" : "+v"(p2));                      // (a second load of the entries, not the first one kept alive across the loss evaluation)
+        EntryCursor ec = entry_cursor(c, p2);
         const double cgd = fx_const(fxg_hi);
         auto grad_entry = [&](const f32x4 &w, uint32_t im) {
             double acc = fma(r[0], (double)w.x, cgd);
@@ -818,11 +841,7 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
         for (int jb = 0; jb < HZREG; jb += EBATCH) {          // the first batch(es) in straight-line code: they include the HZREG leading entries
             f32x4 w[EBATCH];
             uint32_t im[EBATCH];
-#pragma unroll
-            for (int t = 0; t < EBATCH; t++) {
-                w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
-                if (jb + t < kh) { w[t] = c.ell_w4[(size_t)(jb + t) * c.NR + p2]; im[t] = c.ell_im[(size_t)(jb + t) * c.NR + p2]; }
-            }
+            load_entries(c, ec, jb, kh, w, im);
 #pragma unroll
             for (int t = 0; t < EBATCH; t++) {
                 if (jb + t < kh) {
@@ -834,11 +853,7 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
         for (int j0 = HZREG; j0 < kh; j0 += EBATCH) {
             f32x4 w[EBATCH];
             uint32_t im[EBATCH];
-#pragma unroll
-            for (int t = 0; t < EBATCH; t++) {
-                w[t].x = 0.f; w[t].y = 0.f; w[t].z = 0.f; w[t].w = 0.f; im[t] = 0;
-                if (j0 + t < kh) { w[t] = c.ell_w4[(size_t)(j0 + t) * c.NR + p2]; im[t] = c.ell_im[(size_t)(j0 + t) * c.NR + p2]; }
-            }
+            load_entries(c, ec, j0, kh, w, im);
 #pragma unroll
             for (int t = 0; t < EBATCH; t++) if (j0 + t < kh && j0 + t < rp.nnz) grad_entry(w[t], im[t]);
         }
@@ -879,16 +894,16 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
             }
         } else {                                             // runs with more leading entries than the registers hold: from memory
             for (int a = 0; a < rp.hz; a++) {
-                const f32x4 wa = c.ell_w4[(size_t)a * c.NR + p2];
-                const uint32_t ima = c.ell_im[(size_t)a * c.NR + p2];
+                const f32x4 wa = gld(c.ell_w4, ((unsigned)a * (unsigned)c.NR + (unsigned)p2) * 16u);
+                const uint32_t ima = gld(c.ell_im, ((unsigned)a * (unsigned)c.NR + (unsigned)p2) * 4u);
                 const unsigned la = ima >> 16;
                 const int ia = (int)(ima & 0xffffu), rba = rbp[ia];
                 const double dw[SDSM_RUN] = {(la & 1u) ? d[0] * (double)wa.x : 0.0, (la & 2u) ? d[1] * (double)wa.y : 0.0,
                                              (la & 4u) ? d[2] * (double)wa.z : 0.0, (la & 8u) ? d[3] * (double)wa.w : 0.0};
                 theta_rows(ia, dw);
                 for (int b = 0; b <= a; b++) {
-                    const f32x4 wb = c.ell_w4[(size_t)b * c.NR + p2];
-                    const uint32_t imb = c.ell_im[(size_t)b * c.NR + p2];
+                    const f32x4 wb = gld(c.ell_w4, ((unsigned)b * (unsigned)c.NR + (unsigned)p2) * 16u);
+                    const uint32_t imb = gld(c.ell_im, ((unsigned)b * (unsigned)c.NR + (unsigned)p2) * 4u);
                     const unsigned lb = imb >> 16;
                     if (!(la & lb)) continue;
                     double acc = fma(dw[0], (lb & 1u) ? (double)wb.x : 0.0, chd);
@@ -1732,10 +1747,11 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
             const int p = pb + (int)(threadIdx.x & 63);
             const bool active = p < c.p_hi;
             RunPix rp;
-            load_run(c, p, active, rp);
+            const int pl = load_pos(c, p, active);
+            load_run(c, pl, active, rp);
             double Sv[SDSM_RUN];
             poly_surface(rp, x, Sv);
-            if (Mfull > 0) smooth_add<1>(c, x, p, active, chunk_entries(c, pb), Sv);
+            if (Mfull > 0) smooth_add<1>(c, x, pl, chunk_entries(c, pb), Sv);
             if (active) {
                 const uint32_t rc = c.crop_rc[p];
                 const int pr = rc >> 16, pc0 = rc & 0xffffu;
@@ -1822,6 +1838,7 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int h
     // picks an instruction, the pixel passes of the other candidates of the compute unit fill the gaps (+2 % on the 8-image launch).
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x;
+    load_log_table(tid);
     if constexpr (CLS != SDSM_CLS_1 && !WIDE) {              // (class 1 and the groups always take entry b: no second copy of the solver in their kernels)
       if (list >= 0) {
         int *sh = reinterpret_cast<int *>(SD + L::FLAG);
@@ -1865,6 +1882,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     using L = Lay<NMAX, EMAX, GLOBALH, WGSIZE>;
     const int tid = threadIdx.x;
     const int ci = blockIdx.x;
+    load_log_table(tid);
     const CandDesc cd = uniform_desc(P.cand[ci]);
     const CandState st = uniform_state(P.state[ci]);
     if (st.status != ST_OK || st.M < 0 || 6 + st.M > SDSM_MAX_N_SOLVE) return;            // out stays NaN (filled by the host)

@@ -28,7 +28,7 @@ state = ws[lay[1]:lay[1] + int(lay[14]) * batch.n].view(np.int32).reshape(batch.
 env = state[:, 15].astype(np.int64); n = recs['n_deform'] + 6; N = recs['n_pixels']
 p = prof.cpu().numpy()[:len(fps) * 16].reshape(-1, 16).astype(float)
 tot = p[:, 5] / 2.4e6
-k1 = (n <= 128) & (env <= 2560); k1b = ~k1 & (n <= 256) & (env <= 7168); k2 = ~k1 & ~k1b & (env <= 11000); k2b = ~k1 & ~k1b & ~k2 & (n <= 512) & (env <= 15300); k3 = ~k1 & ~k1b & ~k2 & ~k2b
+k1 = (n <= 128) & (env <= 2560); k1b = ~k1 & (n <= 256) & (env <= 7168); k2 = ~k1 & ~k1b & (env <= 11000); k2b = ~k1 & ~k1b & ~k2 & (n <= 512) & (env <= 15170); k3 = ~k1 & ~k1b & ~k2 & ~k2b
 grp = (N > 12288) & (env <= 11000)          # throughput mode: regions of more than 12 288 pixels whose envelope fits class 2 are solved by workgroup groups (while the member budget lasts)
 for nm, m in (('K1', k1 & ~grp), ('K1b', k1b & ~grp), ('K2', k2 & ~grp), ('K2b', k2b), ('K3', k3), ('groups', grp)):
     if m.any():
