@@ -16,7 +16,7 @@ The 8 images of a step are 8 DIFFERENT BBBC039-like images (ellipses at the cent
 regression tables, 68 .. 170 objects).  The default run also measures the other BASELINE.json configs (`extras.configs`: GOWT1-like
 frame, NIH3T3-like image set through the stage, synthetic 4096^2), each with its launch time, solves/s and roofline fraction.
 
-Other workloads: --workload {gowt1_like,nih3t3_like,synthetic4096,synthetic256} (one image per step);
+Other workloads: --workload {gowt1_like,nih3t3_like,synthetic4096,synthetic512,synthetic256} (one image per step unless --images);
 --mode image_set: BASELINE.json configs[3] -- a set of NIH3T3-like images dealt to the ranks, every rank runs the
 global-energy-minimisation stage on its images in lock step (process_many), one gather of the results at the end;
 --mode sharded: BASELINE.json configs[4] as specified -- the candidates of ONE batch (default: the synthetic 4096^2 image) dealt to the
@@ -484,14 +484,18 @@ def extras(args, scene, img, n_images, scenes=None):
     return ex
 
 
-def launch_figures(scene, n_timed=15):
-    """One engine launch over all candidates of one image (throughput scheduling, as the headline step): wall clock per launch, HIP-event
-    time of the solve kernels, solves/s and the roofline fraction by SURVEY.md 8(d)'s byte count."""
+def launch_figures(scene, n_timed=15, copies=1):
+    """One engine launch over all candidates of one image -- or of `copies` images of that shape in one plan -- (throughput scheduling, as
+    the headline step): wall clock per launch, HIP-event time of the solve kernels, solves/s and the roofline fraction by SURVEY.md 8(d)'s
+    byte count."""
     import torch
     from superdsm_amd import _capi, engine
     L = _capi.lib()
     img = engine.DeviceImage(scene['y'], None, scene['atoms'], scene['dsm_cfg']['background_margin'])
-    batch = engine.Batch(img, scene['footprints'], scene['dsm_cfg'])
+    if copies > 1:
+        batch = engine.Batch([img] * copies, scene['footprints'] * copies, scene['dsm_cfg'], image_of=np.repeat(np.arange(copies, dtype=np.int32), len(scene['footprints'])))
+    else:
+        batch = engine.Batch(img, scene['footprints'], scene['dsm_cfg'])
     for _ in range(4):
         batch.launch()
     torch.cuda.synchronize()
@@ -512,8 +516,8 @@ def launch_figures(scene, n_timed=15):
     alg = engine.algorithmic_bytes(recs, batch.mask_info)
     ms = float(np.median(ts))
     kern = float(np.mean(km))
-    return dict(image=f'{scene["y"].shape[0]}x{scene["y"].shape[1]}', candidates=len(scene['footprints']), ms_per_launch=ms, solve_kernels_ms=kern, setup_kernel_ms=float(np.mean(sm)),
-                candidate_solves_per_s=len(scene['footprints']) / (ms * 1e-3), median_N=int(np.median(recs['n_pixels'])), max_N=int(recs['n_pixels'].max()),
+    return dict(image=f'{scene["y"].shape[0]}x{scene["y"].shape[1]}', images_per_launch=copies, candidates=len(scene['footprints']) * copies, ms_per_launch=ms, solve_kernels_ms=kern, setup_kernel_ms=float(np.mean(sm)),
+                candidate_solves_per_s=len(scene['footprints']) * copies / (ms * 1e-3), median_N=int(np.median(recs['n_pixels'])), max_N=int(recs['n_pixels'].max()),
                 median_M=int(np.median(recs['n_deform'])), max_M=int(recs['n_deform'].max()),
                 roofline={'bound': 'hbm', 'achieved': alg / (kern * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / (kern * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': alg},
                 status_counts={str(k): int(v) for k, v in zip(*np.unique(recs['status'], return_counts=True))})
@@ -544,6 +548,10 @@ def other_configs(args):
     out['nih3t3_like'] = dict(fig, stands_for='BASELINE.json configs[3] on ONE GPU: NIH3T3-like images; launch figures for all candidates of one image, and the whole '
                                               'global-energy-minimisation stage on a set of 3 images in lock step (image sets over N GPUs: --mode image_set)',
                               stage_wall_ms_per_image_set_of_3=float(np.median(ts)), stage_candidates_set_of_3=ncand)
+    sc = testing.make_scene('synthetic512', max_size=3)
+    out['synthetic512'] = dict(launch_figures(sc, copies=16), single_image=launch_figures(sc),
+                               stands_for="BASELINE.json north_star: 'candidate-solves/sec on synthetic 512x512 nuclei images': 60 nuclei of radius 15 (some overlapping), "
+                                          'every candidate; one launch over 16 such images (a plan holds up to 16), and one image alone')
     sc = testing.make_scene('synthetic4096', max_size=3)
     out['synthetic4096'] = dict(launch_figures(sc, n_timed=3), stands_for='BASELINE.json configs[4] on ONE GPU: synthetic 4096x4096, ~2000 dense overlapping nuclei, every candidate in one launch '
                                                                            '(over N GPUs as ONE sharded batch: --mode sharded)')

@@ -133,6 +133,7 @@ struct sdsm_plan {
     int setup_class = 2;         // LDS limits of the setup kernel that hold this plan (sdsm_setup_class)
     int mode = 0;                // sdsm_plan_set_latency_mode: 0 throughput, 1 latency, 2 no workgroup groups
     int wide_pixels = INT_MAX;   // throughput mode by default
+    int boost_pixels = INT_MAX;  // regions above run their pixel passes at a raised priority (throughput mode, layout_plan)
     std::vector<float> psf;
     std::vector<int32_t> mask_info, n_pixels;
     std::vector<int64_t> mask_off_bytes, xi_off;
@@ -208,6 +209,9 @@ static uint32_t perm_inverse(uint32_t N)
 #ifndef SDSM_WIDE_TP_MIN_PIXELS
 #define SDSM_WIDE_TP_MIN_PIXELS 8192   // throughput mode: no groups below this many pixels
 #endif
+#ifndef SDSM_K1_PIXDIV
+#define SDSM_K1_PIXDIV 2048             // throughput mode: regions above (pixels of all candidates) / SDSM_K1_PIXDIV pixels leave the 192 / 256-thread classes
+#endif
 #ifndef SDSM_WIDE_FILL
 #define SDSM_WIDE_FILL 1024              // throughput mode: groups only for regions of more than (pixels of all candidates) / SDSM_WIDE_FILL pixels
 #endif
@@ -220,6 +224,7 @@ static void layout_plan(sdsm_plan *p)
     const int n = p->n;
     const bool latency = p->mode == 1, groups = p->mode != 2;
     p->wide_pixels = latency ? SDSM_WIDE_PIXELS : INT_MAX;
+    p->boost_pixels = INT_MAX;
     p->layout_gen++;
     p->n_wide = 0;
     // Groups shorten the longest chains of a launch; every member holds a whole compute unit and a group only advances while all of its
@@ -233,7 +238,21 @@ static void layout_plan(sdsm_plan *p)
         // and groups there cost compute units that the other candidates wait for (75 -> 97 ms with groups for everything above 12 288 pixels)
         long long all_pixels = 0;
         for (int i = 0; i < n; i++) all_pixels += p->cand[i].N;
-        wide_thr = std::max<long long>(SDSM_WIDE_TP_MIN_PIXELS, all_pixels / SDSM_WIDE_FILL);
+        long long tp_min = SDSM_WIDE_TP_MIN_PIXELS;
+        if (const char *e = getenv("SDSM_WIDE_TP_MIN_PIXELS")) { const long long v = atoll(e); if (v > 0) tp_min = v; }   // diagnostic knob
+        wide_thr = std::max<long long>(tp_min, all_pixels / SDSM_WIDE_FILL);
+    }
+    if (!latency) {
+        // Throughput mode: a candidate whose chain (~ its pixels) is long next to the time the plan keeps the chip busy (~ pixels of all
+        // candidates / 1024 workgroup slots of class 1) runs its passes over the pixels at a raised issue priority: regions above 1 /
+        // SDSM_K1_PIXDIV of all pixels.  8 different BBBC039-like images: class 1 took 6.8 ms beside the other classes while its workgroup
+        // time was 3.6 ms of the chip -- its 4-5 ms chains (6-7 k pixels, 95-114 unknowns; 2.8 ms on an idle chip) ended it.  (Moving
+        // them to the 512-thread classes instead, a compute unit each: 7.6 -> 8.7-9.2 ms per step, measured in round 4.)
+        long long all_pixels = 0;
+        for (int i = 0; i < n; i++) all_pixels += p->cand[i].N;
+        long long div = SDSM_K1_PIXDIV;
+        if (const char *e = getenv("SDSM_K1_PIXDIV")) { const long long v = atoll(e); if (v > 0) div = v; else if (v < 0) div = 0; }   // diagnostic knob (negative: no bound)
+        p->boost_pixels = div > 0 ? (int)std::min<long long>(INT_MAX, std::max<long long>(SDSM_WIDE_PIXELS, all_pixels / div)) : INT_MAX;
     }
     auto group_size = [&](long N) -> long {              // members of the group a region of N pixels would get (0: none)
         if (!groups || n >= (1 << 24)) return 0;
@@ -508,10 +527,10 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
 {
     uint8_t *b = (uint8_t *)d_ws;
     BatchParams P{};
-    P.n = p->n; P.n_total = p->n; P.pad_n = 0; P.n_images = (int)p->images.size();
+    P.n = p->n; P.n_total = p->n; P.latency = p->mode == 1; P.n_images = (int)p->images.size();
     for (size_t i = 0; i < p->images.size(); i++) { P.img[i].H = p->images[i].H; P.img[i].W = p->images[i].W; }   // device pointers: filled by the launch
     P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.zcap_run = p->zcap_run; P.zshift = p->zshift; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
-    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels;
+    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels; P.boost_pixels = p->boost_pixels;
     P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
     P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);
     P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);

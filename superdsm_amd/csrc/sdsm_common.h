@@ -126,16 +126,17 @@ struct ImageRef {
 
 struct BatchParams {
     int32_t n, n_images;
-    int32_t n_total, pad_n;            // candidates of the plan (n is the length of the launch list of a kernel)
+    int32_t n_total, latency;          // candidates of the plan (n is the length of the launch list of a kernel); latency mode (256 threads per class-1 candidate)
     ImageRef img[SDSM_MAX_IMAGES];
     int32_t k, R, subsample, zcap;     // PSF size, radius k/2, grid spacing, bound on the entries of one pixel's row of G~
     int32_t zcap_run, zshift;          // bound on the entries of a run (union of <= 4 rows); sort class of a run = (entries + (1 << zshift) - 1) >> zshift
     int32_t no_deform;                 // smooth_amount == inf
     int32_t no_trivial_rule;           // sdsm_dsm_config.flags bit 0: solve even a region with a single positive pixel (cvxprog called directly, c2freganal.py:58-79)
     int32_t init_elliptical, max_iters;
-    int32_t k1_pixmax;                 // regions with more pixels are solved by class 2 (INT_MAX: throughput mode)
+    int32_t k1_pixmax;                 // regions with more pixels are solved by the 512-thread classes (layout_plan: a fixed bound in latency mode, relative to the plan's pixels in throughput mode)
     double scale, epsilon, alpha;
-    float hess_thr; int32_t pad1;      // Hessian ignores row entries < hess_thr * row maximum (solver approximation)
+    float hess_thr;                    // Hessian ignores row entries < hess_thr * row maximum (solver approximation)
+    int32_t boost_pixels;              // throughput mode: regions with more pixels run their passes over the pixels at a raised issue priority (the long chains of a launch; layout_plan)
     const CandDesc *cand;
     CandState *state;
     const int32_t *fp_labels;

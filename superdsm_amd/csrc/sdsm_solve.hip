@@ -118,6 +118,7 @@ struct Cand {                       // per-candidate global pointers (already of
     double scale, epsilon, alpha;
     double reg0;                        // alpha * sqrt(epsilon) * M: the regulariser's value at xi = 0 (dsm.py:325-326)
     int yexp;                           // |y| < 2^yexp over the region (setup kernel): scale of the fixed-point sums (fx_exponents)
+    int boost;                          // a long chain of its launch (BatchParams.boost_pixels): passes over the pixels at a raised issue priority
 };
 
 // The evaluators are real (non-inlined) functions and receive the candidate by reference: its fields then come out of a
@@ -164,7 +165,7 @@ __device__ __forceinline__ Cand uniform_cand(const Cand &c)
     u.p_lo = uni(c.p_lo); u.p_hi = uni(c.p_hi); u.wg = uni(c.wg); u.wG = uni(c.wG); u.wpool = (double *)uni((unsigned long long)c.wpool); u.wtimeout = uni(c.wtimeout);
     u.rmid = uni(c.rmid); u.cmid = uni(c.cmid); u.inv_hr = uni(c.inv_hr); u.inv_hc = uni(c.inv_hc);
     u.scale = uni(c.scale); u.epsilon = uni(c.epsilon); u.alpha = uni(c.alpha); u.reg0 = uni(c.reg0);
-    u.yexp = uni(c.yexp);
+    u.yexp = uni(c.yexp); u.boost = uni(c.boost);
     return u;
 }
 
@@ -402,6 +403,14 @@ __device__ __forceinline__ void loss_terms(double yv, double S, double *phi, dou
 // chunks than fit there are walked in segments.  wG > 1: the super-chunk sums are PUBLISHED, the caller completes the exchange
 // (wide_finish); tot is then undefined here.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef SDSM_BOOST_PRIO
+#define SDSM_BOOST_PRIO 1
+#endif
+__device__ __forceinline__ void pass_priority(const Cand &c)
+{
+    if (c.boost) __builtin_amdgcn_s_setprio(SDSM_BOOST_PRIO); else __builtin_amdgcn_s_setprio(0);
+}
+
 template <class L, int K, class Body>
 __device__ __forceinline__ void run_pass(const Cand &c, double (&tot)[K], Body &&body)
 {
@@ -416,7 +425,7 @@ __device__ __forceinline__ void run_pass(const Cand &c, double (&tot)[K], Body &
     int npub = 0;
     for (int seg0 = c.p_lo; seg0 < c.p_hi; seg0 += SEGC * 64) {
         const int seg1 = seg0 + SEGC * 64 < c.p_hi ? seg0 + SEGC * 64 : c.p_hi;
-        __builtin_amdgcn_s_setprio(0);
+        pass_priority(c);
         for (int pb = seg0 + (tid & ~63); pb < seg1; pb += L::WGS) {
             const int p = pb + lane;
             double v[K];
@@ -445,15 +454,22 @@ __device__ __forceinline__ void run_pass(const Cand &c, double (&tot)[K], Body &
                 for (int k = 0; k < K; k++) acc[k] += part[k];
             }
         } else {
+            // The publication block holds the super-chunk sums of a slice of the largest admissible region dealt to the largest group
+            // (static_assert below); a smaller group of such a region (latency mode) does not fit: the group is given up -- flagged, every
+            // member sees it at the next exchange, the host solves the candidate again without a group -- instead of losing sums.
+            static_assert(SDSM_WIDE_FCAP - 8 >= LS_K * (((long long)SDSM_MAX_BBOX_DIM * (SDSM_MAX_BBOX_DIM / SDSM_RUN)) / ((long long)SDSM_WIDE_MAX_G * 64 * SDSM_SUPER)),
+                          "SDSM_WIDE_FCAP: super-chunk sums of one member's slice");
             const int nsc = (nch + SDSM_SUPER - 1) / SDSM_SUPER;
-            for (int t = tid; t < nsc * K; t += L::WGS) {
+            const bool fits = npub + nsc * K <= SDSM_WIDE_FCAP - 8;
+            if (!fits && tid == 0) __hip_atomic_store(reinterpret_cast<int *>(c.wpool) + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int t = tid; fits && t < nsc * K; t += L::WGS) {
                 const int sc = (t / K) * SDSM_SUPER, k = t % K;
                 const int e1 = sc + SDSM_SUPER < nch ? sc + SDSM_SUPER : nch;
                 double part = 0;
                 for (int i = sc; i < e1; i++) part += ct[i * K + k];
-                if (npub + t < SDSM_WIDE_FCAP - 8) pub[1 + npub + t] = part;
+                pub[1 + npub + t] = part;
             }
-            npub += nsc * K;
+            if (fits) npub += nsc * K;
         }
         __syncthreads();                                             // ct is rewritten by the next segment / the next pass
     }
@@ -735,13 +751,16 @@ __device__ __forceinline__ void fx_add(double *addr, double a, double b, int chi
 // a single 48-bit word below the LARGEST possible term (not the largest actual one: |y| is small where theta^ is large) lost 3-4
 // digits against the reference's float64 sums there, and a handful of such solves ran into the iteration cap.
 #define FX_LO_SHIFT 48
+// The two words are added RAW -- the bits of C + k unit are the bits of C plus the integer k --: the accumulator then holds the sum of
+// the integers plus (number of additions) * (high word of C) << 32, and the number of additions into the moment slots is known (one
+// per run of the slice): eval_full takes it off the slot totals.  One instruction less per word than fx_commit.
 __device__ __forceinline__ void fx_add2(double *addr, double a, double b, int chi)
 {
     const double c1 = fx_const(chi);
     const double s1 = fma(a, b, c1);
     const double res = fma(a, b, c1 - s1);                   // a b - (s1 - c1): exact to 2^-53 of itself, |res| <= unit / 2
-    fx_commit(addr, s1, chi);
-    fx_commit(addr + NSLOT, res + fx_const(chi - (FX_LO_SHIFT << 20)), chi - (FX_LO_SHIFT << 20));
+    atomicAdd(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(s1));
+    atomicAdd(reinterpret_cast<unsigned long long *>(addr + NSLOT), (unsigned long long)__double_as_longlong(res + fx_const(chi - (FX_LO_SHIFT << 20))));
 }
 __device__ __forceinline__ double fx_get2(double hi, double lo, double unit)
 {
@@ -802,13 +821,13 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
         // moments of the run: u^a * sum_k (r_k | d_k) v_k^b
         const double u = rp.u, uu = u * u;
         double R0 = 0, R1 = 0, R2 = 0, D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0;
-        bool anynz = false;
+        bool anynz = false;                                  // (r = -y theta^ = 0 implies d = y^2 theta^ (1 - theta^) = 0)
 #pragma unroll
         for (int k = 0; k < SDSM_RUN; k++) {
             const double vk = rp.v[k], vv = vk * vk, dvv = d[k] * vv;
             R0 += r[k]; R1 = fma(r[k], vk, R1); R2 = fma(r[k], vv, R2);
             D0 += d[k]; D1 = fma(d[k], vk, D1); D2 += dvv; D3 = fma(dvv, vk, D3); D4 = fma(dvv, vv, D4);
-            anynz = anynz || d[k] != 0 || r[k] != 0;
+            anynz = anynz || r[k] != 0;
         }
         {
             const int cg = fxg_hi, ch = fxh_hi;
@@ -920,6 +939,9 @@ __device__ __forceinline__ double eval_full(const Cand &c, int M, double reg_mu,
     if (tid < 42) {
         unsigned long long sacc = 0;
         for (int i = 0; i < NSLOT; i++) sacc += msl[tid * NSLOT + i];
+        // every run of the slice added the bits of its constant along with its integer (fx_add2): word tid belongs to moment tid / 2
+        const unsigned chi_w = (unsigned)(tid < 12 ? fxg_hi : fxh_hi) - ((tid & 1) ? (unsigned)(FX_LO_SHIFT << 20) : 0u);
+        sacc -= (unsigned long long)((unsigned)(c.p_hi - c.p_lo) * chi_w) << 32;
         mraw[tid] = sacc;
     }
     __syncthreads();
@@ -1613,7 +1635,7 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
     c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * Mfull;   // (only read by passes with M = Mfull > 0)
-    c.yexp = st.yexp;
+    c.yexp = st.yexp; c.boost = cd.N > P.boost_pixels;
     // local frame: centre of the bounding box, half extents
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
@@ -1624,6 +1646,7 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
 #ifdef SDSM_PROFILE
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long prof_t_start = PROF_NOW();
+    prof_acc[7] = wall_clock64();                               // 100 MHz wall clock: when this candidate's workgroup started ...
 #endif
     sdsm_record r = {};
     r.n_pixels = cd.N; r.n_deform = st.M;
@@ -1742,7 +1765,7 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
     int rmin = 1 << 30, rmax = -1, cmin = 1 << 30, cmax = -1;
     int onb = 0;
     if (status_final != SDSM_CAND_ERROR) {
-        __builtin_amdgcn_s_setprio(0);
+        pass_priority(c);
         for (int pb = c.p_lo + (opaque_tid() & ~63); pb < c.p_hi; pb += L::WGS) {
             const int p = pb + (int)(threadIdx.x & 63);
             const bool active = p < c.p_hi;
@@ -1815,6 +1838,7 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
         r.on_boundary = onb;
 #ifdef SDSM_PROFILE
         prof_acc[5] = PROF_NOW() - prof_t_start;
+        prof_acc[12] = wall_clock64();                          // ... and ended (tools/class_stats.py: who ends the launch, and when it began)
         if (P.prof) for (int i = 0; i < 16; i++) P.prof[(size_t)ci * 16 + i] = prof_acc[i];
 #endif
         if (rmax >= 0) { r.fg_r0 = rmin; r.fg_c0 = cmin; r.fg_h = rmax - rmin + 1; r.fg_w = cmax - cmin + 1; }
@@ -1899,7 +1923,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     c.ell_im = (g_cu32_p)(P.ell_im + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(reinterpret_cast<const f32x4 *>(P.ell_w) + cd.ell_off);
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N; c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * M;
-    c.yexp = st.yexp;
+    c.yexp = st.yexp; c.boost = 0;
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
     c.inv_hr = 1.0 / (half_r < 1 ? 1 : half_r); c.inv_hc = 1.0 / (half_c < 1 ? 1 : half_c);
@@ -2094,7 +2118,7 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     // priorities change nothing).  The few long candidates of the large classes ARE the end of the launch: class 1 starts some tens of
     // microseconds after them -- their resident workgroups are in place by then, the ones without work gone again.
     if (n_c > 0 || n_d > 0 || n_w > 0) hipLaunchKernelGGL(sdsm_k_head_start, dim3(1), dim3(64), 0, stream, (long long)SDSM_HEAD_START_US * 100);
-    if (P.k1_pixmax == INT_MAX) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
+    if (!P.latency) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
     else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
     if (e != hipSuccess) return e;
     // join

@@ -663,14 +663,18 @@ class GlobalEnergyMinimization(Stage):
             assert set(prod.keys()) == set(self.outputs), 'stage "%s" generated unexpected output' % self.name
             for inner, outer in self.outputs.items():
                 data[outer] = prod[inner]
-        for i, e in enumerate(errors):
-            if e is not None:
-                e.image_index = i
-                raise e
-        for data, prod in ():
-            assert set(prod.keys()) == set(self.outputs), 'stage "%s" generated unexpected output' % self.name
-            for inner, outer in self.outputs.items():
-                data[outer] = prod[inner]
+        failed = [i for i, e in enumerate(errors) if e is not None]
+        if failed:
+            e = errors[failed[0]]
+            # a failure of the batch as a whole (not of one image's candidate) reaches every image thread as the SAME exception object:
+            # it then carries all of their indices, not the first one
+            shared = [i for i in failed if errors[i] is e]
+            try:
+                e.image_index = failed[0]
+                e.image_indices = shared
+            except AttributeError:                # (an exception type without a __dict__)
+                pass
+            raise e
         return time.time() - t0
 
     def configure_ex(self, scale, radius, diameter):

@@ -168,6 +168,18 @@ class MinSetCover:
         merge, max_iter, gamma = kw.get('merge', True), kw.get('max_iter', DEFAULT_MAX_ITER), kw.get('gamma', DEFAULT_GAMMA)
         native = []
         for cl in touched:                                   # objects without energies yet / non-finite ones: the Python restatement
+            objs = self.objects_by_cluster[cl]
+            index, masks, _ = self._bits[cl]
+            # The reference reads `energy` and `footprint` of every object when it solves (minsetcover.py:24-36), not when the object was
+            # added: energies are taken afresh from the objects here, and objects that reached the public list by another way than
+            # update() get their bit sets now
+            for obj in objs[len(masks):]:
+                m = 0
+                for a in obj.footprint:
+                    m |= 1 << index.setdefault(a, len(index))
+                masks.append(m)
+            assert len(masks) == len(objs), 'objects were removed from objects_by_cluster'
+            self._bits[cl] = (index, masks, [o.energy for o in objs])
             e = self._bits[cl][2]
             if all(v is not None and v == v and abs(v) != float('inf') for v in e):
                 native.append(cl)

@@ -150,6 +150,7 @@ def enumerate_candidates(adjacencies, max_size=3):
 # hyper-parameters per BASELINE.json config (derived-parameter table)
 WORKLOADS = {
     'synthetic256': dict(shape=(256, 256), n=10, radius=15, seed=1001, scale=10),
+    'synthetic512': dict(shape=(512, 512), n=60, radius=15, seed=1006, scale=10),     # BASELINE.json north_star: 'synthetic 512x512 nuclei images'
     'bbbc039_like': dict(seed=1002, scale=10),
     'gowt1_like':   dict(shape=(1024, 1024), n=25, radius=31, seed=1003, scale=42.43),
     'nih3t3_like':  dict(shape=(1344, 1024), n=48, radius=43, seed=1004, scale=40),

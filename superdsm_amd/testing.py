@@ -16,8 +16,8 @@ def make_scene(workload='synthetic256', max_size=3, alpha_factor=None, layout_in
         af = 0.00033 if alpha_factor is None else alpha_factor       # examples/BBBC039/task.json: AF_alpha
     else:
         shape = spec['shape']
-        layout = synth.random_layout(shape, spec['n'], spec['radius'], spec['seed'], min_sep=0.6 if workload == 'synthetic4096' else 2.2)
-        af = {'synthetic256': 0.00033, 'synthetic4096': 0.00033, 'gowt1_like': 0.0005, 'nih3t3_like': 0.000375}[workload] if alpha_factor is None else alpha_factor
+        layout = synth.random_layout(shape, spec['n'], spec['radius'], spec['seed'], min_sep={'synthetic4096': 0.6, 'synthetic512': 1.2}.get(workload, 2.2))
+        af = {'synthetic256': 0.00033, 'synthetic512': 0.00033, 'synthetic4096': 0.00033, 'gowt1_like': 0.0005, 'nih3t3_like': 0.000375}[workload] if alpha_factor is None else alpha_factor
     g = synth.render_image(shape, layout, spec['seed'])
     y = synth.offset_image(g, spec['scale'])
     atoms, clusters, seeds = synth.make_atoms(y, layout, spec['seed'])

@@ -251,14 +251,18 @@ def tight_minimum(J, x0, scale):
     return x, J(x), gnorm
 
 
-def gen_optimum(scene, tag, cfg):
+def gen_optimum(scene, tag, cfg, picks=None):
     g, y, atoms, clusters, seeds = scene
     yimg = rimage.Image.create_from_array(y, normalize=False, mask=np.ones(y.shape, bool))
     x_map = yimg.get_map(normalized=False, pad=1)
     adj = superdsm.atoms.AtomAdjacencyGraph(atoms, clusters, y > 0, seeds, out='muted')
     cands = synth.enumerate_candidates(adj, max_size=2)
     # keep it small: the first few atoms, a few unions, one universe
-    picks = [c for c in cands if len(c) == 1][:4] + [c for c in cands if len(c) == 2][:3] + [c for c in cands if len(c) > 2][:1]
+    if picks is None:
+        picks = [c for c in cands if len(c) == 1][:4] + [c for c in cands if len(c) == 2][:3] + [c for c in cands if len(c) > 2][:1]
+    else:
+        cands = synth.enumerate_candidates(adj, max_size=max(len(p) for p in picks))
+        assert all(sorted(int(v) for v in p) in [sorted(int(v) for v in c) for c in cands] for p in picks), 'picks must be candidates of the scene'
     out = dict(y=y, atoms=atoms.astype(np.int32), clusters=clusters.astype(np.int32), seeds=np.asarray(seeds),
                cfg=json.dumps(cfg), n_cases=np.asarray(len(picks)))
     for k, fp in enumerate(picks):
@@ -477,6 +481,10 @@ def main():
         gen_optimum(scene, 'bbbc039_params', DSM_CFG)
         scene2 = make_scene((200, 220), 4, 34, 32, sigma2=20)
         gen_optimum(scene2, 'large_sigma', dict(DSM_CFG, smooth_amount=8, smooth_subsample=16, background_margin=16, alpha=0.9))
+    if 'optimum' in what or 'optimum_large' in what:
+        # systems beyond the small solve classes (round 4): 6 + M in (128, 256], (256, 512], > 512, Hessian envelopes beyond LDS
+        scene4 = make_scene((260, 300), 5, 40, 41, sigma2=20)
+        gen_optimum(scene4, 'large_systems', dict(DSM_CFG, smooth_subsample=4), picks=[[9, 10], [5, 7], [3, 4, 5], [7, 8]])
     if 'config' in what: gen_config()
     if 'setcover' in what:
         scene3 = make_scene((160, 200), 14, 12, 33, sigma2=10)

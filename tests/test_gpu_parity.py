@@ -59,7 +59,7 @@ def test_image_prepare_matches_oracle(gpu):
 # ---------------------------------------------------------------------------------------------------------
 # setup kernel: region crops, greedy grid, float32-exact G~ rows (dsm.py:137-237)
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma'])
+@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma', 'large_systems'])
 def test_setup_matches_oracle_exactly(gpu, tag):
     from oracle import oracle
     from superdsm_amd import engine
@@ -137,7 +137,7 @@ def _paste(off, frag, shape):
     return out
 
 
-@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma'])
+@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma', 'large_systems'])
 def test_solve_reaches_reference_optima(gpu, tag):
     from oracle import oracle
     from superdsm_amd import _capi, testing
@@ -191,6 +191,33 @@ def test_solve_matches_oracle_on_synthetic256(gpu):
         dice = testing.dice(frags[k][0], frags[k][1], orecs['fg_offset'][k], ofrags[k], scene['y'].shape)
         worst_dice = min(worst_dice, dice)
     assert worst_dice >= 0.999, worst_dice
+
+
+def test_solve_matches_oracle_on_synthetic512(gpu):
+    """BASELINE.json north_star's reporting config -- a synthetic 512x512 nuclei image --: every candidate, GPU vs CPU oracle (energies,
+    status, boundary flag, masks), alone and as one of two images of a plan (the same bytes)."""
+    from oracle import oracle
+    from superdsm_amd import engine, testing
+    scene = testing.make_scene('synthetic512', max_size=3)
+    res = testing.solve_scene_gpu(scene)
+    recs, frags = res['records'], res['fragments']
+    orecs, ofrags, _ = oracle.compute_objects(scene['y'], None, scene['atoms'], scene['footprints'], scene['dsm_cfg'], nthreads=0)
+    n = len(scene['footprints'])
+    assert n > 200 and recs['n_deform'].max() + 6 > 128, 'the scene is meant to reach beyond solve class 1'
+    np.testing.assert_array_equal(recs['n_pixels'], orecs['N'])
+    np.testing.assert_array_equal(recs['n_deform'], orecs['M'])
+    for k in range(n):
+        assert recs['status'][k] == orecs['status'][k], (k, recs['status'][k], orecs['status'][k])
+        tol = 1e-6 * orecs['N'][k] / 1000 + 1e-5 * abs(orecs['energy'][k])
+        assert abs(recs['energy'][k] - orecs['energy'][k]) <= tol, (k, recs['energy'][k], orecs['energy'][k])
+        assert bool(recs['on_boundary'][k]) == bool(orecs['on_boundary'][k])
+        assert testing.dice(frags[k][0], frags[k][1], orecs['fg_offset'][k], ofrags[k], scene['y'].shape) >= 0.999, k
+    img = res['image']
+    two = engine.Batch([img, img], scene['footprints'] * 2, scene['dsm_cfg'], image_of=np.repeat(np.arange(2, dtype=np.int32), n))
+    two.launch()
+    gpu.cuda.synchronize()
+    r2 = two.records()
+    assert r2[:n].tobytes() == recs.tobytes() and r2[n:].tobytes() == recs.tobytes()
 
 
 def test_full_size_properties_bbbc039_like(gpu):
@@ -475,10 +502,10 @@ def test_sharder_single_rank_equals_direct_batch(gpu):
         cfg = {k: v for k, v in scene['dsm_cfg'].items() if k != 'background_margin'}
         recs, frags = sdist.Sharder(device='cpu').solve(img, fps, cfg)
         ref = testing.solve_scene_gpu(scene)
-        np.testing.assert_allclose(recs['energy'], ref['records']['energy'], rtol=1e-6, atol=1e-9)
-        # two runs of the solver differ in the summation order of the LDS atomics: masks agree up to pixels with S ~ 0
+        # a candidate's record does not depend on its plan (every sum over the pixels is an integer sum or a sum in a fixed order): the same bytes
+        assert recs.tobytes() == ref['records'].tobytes()
         for a, b in zip(frags, ref['fragments']):
-            assert testing.dice(a[0], a[1], b[0], b[1], scene['y'].shape) >= 0.999
+            assert tuple(a[0]) == tuple(b[0]) and np.array_equal(a[1], b[1])
     finally:
         if created:
             dist.destroy_process_group()
@@ -541,7 +568,7 @@ def test_collectives_of_the_multi_gpu_paths_run_on_rccl_with_one_rank(gpu):
     assert res[0] == 'ok', res[1]
     _, ok1, tmax, e_shard, e_direct, got = res
     assert ok1 and tmax == 1.5
-    np.testing.assert_allclose(e_shard, e_direct, rtol=1e-9)
+    assert e_shard == e_direct                           # (the same bits: a candidate's numbers do not depend on its plan)
     assert got == [[(0, [[1, 2]], 3.5, 7)]]
 
 
@@ -561,9 +588,9 @@ def test_latency_mode_gives_the_same_results(gpu):
     (r0, f0), (r1, f1) = out
     assert (r0['n_pixels'] > 3072).any(), 'the sample must contain regions that change class'
     assert (r0['status'] == r1['status']).all() and (r0['n_deform'] == r1['n_deform']).all()
-    np.testing.assert_allclose(r1['energy'], r0['energy'], rtol=1e-6, atol=1e-9)
+    assert r1.tobytes() == r0.tobytes()                  # ... nothing else: the same records, the same masks
     for a, b in zip(f0, f1):
-        assert testing.dice(a[0], a[1], b[0], b[1], scene['y'].shape) >= 0.999
+        assert tuple(a[0]) == tuple(b[0]) and np.array_equal(a[1], b[1])
 
 
 def test_wide_envelope_and_long_rows_use_the_global_memory_class(gpu):
@@ -738,7 +765,7 @@ def test_workgroup_group_elliptical_only_and_trivial_cases(gpu):
 # round 2: the fixtures of the reference's elliptical optimum / parameters, point evaluations, BASELINE configs[4],
 # forced protocol branches
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma'])
+@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma', 'large_systems'])
 def test_elliptical_optimum_and_parameters_match_reference(gpu, tag):
     """`c{k}_psi_ell` (the reference's Energy of the 6-parameter model driven to its optimum: ALL of what the C2F operator
     returns), the moment initialisation's energy, and the DSM optimum's parameters theta / xi (`c{k}_x_dsm`)."""
@@ -763,9 +790,14 @@ def test_elliptical_optimum_and_parameters_match_reference(gpu, tag):
             # the optimum is only determined to the solver's stopping accuracy (cond(Hessian) ~ 1e9 in these coordinates)
             assert np.abs(th - x[:6]).max() <= 5e-3 * np.abs(x[:6]).max(), (k, th, x[:6])
             if M:
-                assert np.abs(xi - x[6:]).max() <= 5e-3 * max(1.0, np.abs(x[6:]).max()), k
+                # (systems of several hundred unknowns -- `large_systems` -- have flat directions: grid points that few pixels see, under a
+                # regulariser that is all but linear at |xi| ~ 1e3; the stopping rule lambda^2 / 2 <= 1e-7 + 1e-6 f leaves them undetermined to a
+                # few per cent of the scale while the energy is within 1e-6 relative -- the CPU oracle ends at the same xi as the GPU there)
+                loose = tag == 'large_systems'
+                assert np.abs(xi - x[6:]).max() <= (5e-2 if loose else 5e-3) * max(1.0, np.abs(x[6:]).max()), k
+                assert np.linalg.norm(xi - x[6:]) <= (5e-2 if loose else 5e-3) * max(1.0, np.linalg.norm(x[6:])), k
             checked += 1
-    assert checked >= 6
+    assert checked >= (4 if tag == 'large_systems' else 6)
 
 
 def test_point_evaluations_match_reference_energy(gpu):
@@ -1194,8 +1226,8 @@ def test_generations_solved_ahead_give_the_same_stage_results_in_fewer_batches(g
         d = runs[depth]
         assert sorted(sorted(int(a) for a in o.footprint) for o in d['cover'].solution) == sorted(sorted(int(a) for a in o.footprint) for o in plain['cover'].solution)
         assert [sorted(o.footprint) for o in d['objects']] == [sorted(o.footprint) for o in plain['objects']]
-        np.testing.assert_allclose([o.energy for o in d['objects']], [o.energy for o in plain['objects']], rtol=1e-9)
-        assert abs(d['cover'].costs - plain['cover'].costs) <= 1e-9 * abs(plain['cover'].costs)
+        assert [o.energy for o in d['objects']] == [o.energy for o in plain['objects']]          # the same bits
+        assert d['cover'].costs == plain['cover'].costs
         for k in d['performance'].attributes:
             assert getattr(d['performance'], k) == getattr(plain['performance'], k)
     assert runs[None]['performance'].engine_batches <= 5 and runs[2]['performance'].engine_batches <= 4    # 8 batches without

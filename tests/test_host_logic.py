@@ -469,3 +469,37 @@ def test_cover_update_solves_all_touched_clusters_in_one_native_call():
         for cl in (1, 2, 3):
             ref = minsetcover.solve_minsetcover(cover.objects_by_cluster[cl], 25.0)
             assert [id(o) for o in cover.solution_by_cluster[cl]] == [id(o) for o in ref]
+
+
+def test_disk_morphology_from_the_definition():
+    """`_morph` (the scikit-image calls of the reference's downstream stages, postprocess.py:155,258-262,270,321, render.py:380-384)
+    against the DEFINITIONS, not against another SciPy call (the fixtures of postprocess.npz / render.npz were made with the same SciPy
+    restatement, so they cannot pin it): disk(r) = {dy^2 + dx^2 <= r^2} of a (2r+1)^2 window (literal footprints for r = 1, 2, 3 as the
+    scikit-image documentation prints them); dilation = union of the footprint translated to every set pixel, clipped to the image;
+    erosion = the pixels whose translated footprint, as far as it lies inside the image, is all set (the image border does not erode)."""
+    from superdsm_amd import _morph
+    np.testing.assert_array_equal(_morph.disk(1), [[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    np.testing.assert_array_equal(_morph.disk(2), [[0, 0, 1, 0, 0], [0, 1, 1, 1, 0], [1, 1, 1, 1, 1], [0, 1, 1, 1, 0], [0, 0, 1, 0, 0]])
+    np.testing.assert_array_equal(_morph.disk(3), [[0, 0, 0, 1, 0, 0, 0], [0, 1, 1, 1, 1, 1, 0], [0, 1, 1, 1, 1, 1, 0], [1, 1, 1, 1, 1, 1, 1],
+                                                   [0, 1, 1, 1, 1, 1, 0], [0, 1, 1, 1, 1, 1, 0], [0, 0, 0, 1, 0, 0, 0]])
+    rng = np.random.default_rng(3)
+    for shape, density in (((17, 23), 0.08), ((12, 9), 0.5), ((20, 20), 0.9), ((5, 31), 0.3)):
+        img = rng.random(shape) < density
+        img[0, :3] = True                                   # pixels on the border and in a corner
+        img[-1, -1] = True
+        for r in (1, 2, 3, 5):
+            fp = _morph.disk(r)
+            offs = [(dy - r, dx - r) for dy in range(2 * r + 1) for dx in range(2 * r + 1) if fp[dy, dx]]
+            dil = np.zeros(shape, bool)
+            ero = np.ones(shape, bool)
+            for y in range(shape[0]):
+                for x in range(shape[1]):
+                    for dy, dx in offs:
+                        yy, xx = y + dy, x + dx
+                        if 0 <= yy < shape[0] and 0 <= xx < shape[1]:
+                            if img[y, x]:
+                                dil[yy, xx] = True
+                            if not img[yy, xx]:
+                                ero[y, x] = False
+            np.testing.assert_array_equal(_morph.binary_dilation(img, fp), dil)
+            np.testing.assert_array_equal(_morph.binary_erosion(img, fp), ero)

@@ -109,7 +109,7 @@ def test_energy_value_grad_hessian():
     assert n_guard > 0, 'the exp() guard path (dsm.py:298-300) must be exercised by at least one case'
 
 
-@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma'])
+@pytest.mark.parametrize('tag', ['bbbc039_params', 'large_sigma', 'large_systems'])
 def test_tight_optima_and_mask_tail(tag):
     d = np.load(os.path.join(G, f'optimum_{tag}.npz'))
     cfg = json.loads(str(d['cfg']))

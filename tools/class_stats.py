@@ -42,3 +42,23 @@ print('factor_solve parts of the slowest candidates, ms: head | diag block, trai
 for k in np.argsort(-tot)[:6]:
     print('  N=%d M=%d: %.2f | %.2f %.2f %.2f %.2f | %.2f | %.2f   (factorisations: %d)' % (N[k], recs['n_deform'][k], p[k, 13] / 2.4e6, p[k, 8] / 2.4e6, p[k, 9] / 2.4e6, p[k, 10] / 2.4e6, p[k, 11] / 2.4e6,
                                                                                           p[k, 14] / 2.4e6, p[k, 15] / 2.4e6, recs['evals_full'][k]))
+
+# when the workgroups of the launch started and ended (100 MHz wall clock, relative to the first start): who ends the launch
+st, en = p[:, 7] / 1e5, p[:, 12] / 1e5
+ok = (st > 0) & (en > 0)
+t0 = st[ok].min()
+st, en = st - t0, en - t0
+print('launch span (first workgroup start to last end): %.2f ms' % en[ok].max())
+cls = np.where(grp, 5, np.where(k1, 0, np.where(k1b, 1, np.where(k2, 2, np.where(k2b, 3, 4)))))
+names = ['K1', 'K1b', 'K2', 'K2b', 'K3', 'groups']
+for c in range(6):
+    m = ok & (cls == c)
+    if m.any():
+        print('  %-6s first start %.2f  last start %.2f  last end %.2f   workgroup-ms started in [0,1) [1,2) [2,3) [3,4) [4,5) [5,..): %s' % (
+            names[c], st[m].min(), st[m].max(), en[m].max(), ' '.join('%.0f' % tot[m & (st >= a) & (st < b)].sum() for a, b in ((0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 99)))))
+print('the last 15 to end (end, start, duration ms, class, N, M):')
+for k in np.argsort(-np.where(ok, en, -1))[:15]:
+    print('  end %.2f start %.2f dur %.2f %s N=%d M=%d' % (en[k], st[k], en[k] - st[k], names[cls[k]], N[k], recs['n_deform'][k]))
+# residency: workgroups of class 1 running at time t
+for t in (0.25, 0.5, 1, 2, 3, 4, 5, 6):
+    print('  t=%.2f ms: running K1 %d  K1b %d  others %d' % (t, int((ok & (cls == 0) & (st <= t) & (en > t)).sum()), int((ok & (cls == 1) & (st <= t) & (en > t)).sum()), int((ok & (cls > 1) & (st <= t) & (en > t)).sum())))

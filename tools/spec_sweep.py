@@ -1,6 +1,6 @@
 """Diagnostic: wall time of the stage on single BBBC039-like images against the depth / budget of the generations solved ahead (PRUNING=exact|isbi24)."""
 import os, sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from superdsm_amd import globalenergymin, testing
 from superdsm_amd.output import get_output
 out = get_output('muted')

@@ -1,6 +1,6 @@
 # Diagnostic: bench lines of alternative builds (superdsm_amd/libsdsm_hip_<name>.so) on the workloads of the bench
 # usage: bash tools/variant_bench.sh lib1.so lib2.so ...   (WLS="bbbc039_like|bbbc039_like --same-layout|synthetic4096" to choose)
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 IFS='|' read -ra wls <<< "${WLS:-bbbc039_like|bbbc039_like --same-layout|gowt1_like|nih3t3_like|synthetic4096}"
 for lib in "$@"; do
   for wl in "${wls[@]}"; do
