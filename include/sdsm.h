@@ -259,9 +259,15 @@ double sdsm_last_setup_kernel_ms(void);
 /* Diagnostic builds only (-DSDSM_PROFILE): device buffer receiving 8 int64 cycle counters per candidate
  * (phase A, phase B, reductions, factor+solve, line search, total, elliptical total, reserved). */
 int sdsm_set_debug_buffer(void *d_buf);
-/* Diagnostic: microseconds a member of a workgroup group waits for its partners before the group gives its candidate up
- * (SDSM_CAND_GIVEN_UP); <= 0 restores the default of 10 s.  Applies to the launches of the calling thread. */
+/* Microseconds a member of a workgroup group waits for its partners at one exchange before the group gives its candidate up
+ * (SDSM_CAND_GIVEN_UP: the caller solves it again in a plan without groups, sdsm_plan_set_latency_mode(plan, 2)); <= 0 restores the
+ * default of 50 ms.  Applies to the launches of the calling thread. */
 int sdsm_set_group_timeout_us(double us);
+/* A launch runs its solve classes on the caller's stream and three side streams of the library.  1: they ran side by side when the
+ * library probed them (first launch that needed them); 0: they share hardware queues (GPU_MAX_HW_QUEUES was too small when the process
+ * first touched the GPU) -- launches are correct but their classes run one after the other, a warning went to stderr once; -1: not
+ * probed yet.  No reference counterpart (the reference's parallelism is Ray, objects.py:270-284). */
+int sdsm_side_queues_distinct(void);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,7 @@ SYMBOLS = {
     'sdsm_last_setup_kernel_ms': (_f64, []),
     'sdsm_set_debug_buffer': (_i32, [_vp]),
     'sdsm_set_group_timeout_us': (_i32, [_f64]),
+    'sdsm_side_queues_distinct': (_i32, []),
 }
 
 _lib = None

@@ -119,7 +119,7 @@ struct PlanImage { int H, W, n_atoms; };
 // destroyed: creating and destroying HIP streams costs milliseconds (hipStreamDestroy synchronises), a reference-style caller
 // builds a plan per batch.  A set carries no state between users (events are recorded before they are waited for).
 #include <mutex>
-struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; int device; std::mutex enqueue; };
+struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; int device; std::mutex enqueue; int queues = 0; int32_t *probe_words = nullptr; };   // queues: 0 not probed yet, 1 the four streams run side by side, -1 they share hardware queues
 struct sdsm_plan {
     int n = 0;
     std::vector<PlanImage> images;             // one entry for sdsm_plan_create, several for sdsm_plan_create_multi
@@ -512,9 +512,39 @@ extern "C" int sdsm_batch_upload(const sdsm_plan *p, void *d_ws, size_t ws_bytes
 }
 
 static thread_local long long *g_prof = nullptr;
-static thread_local long long g_wide_timeout = 1000000000ll;   // ticks of the 100 MHz wall clock: 10 s
-// Diagnostic: time a member of a workgroup group waits for its partners before the group is given up (default 1e7 us).
-extern "C" int sdsm_set_group_timeout_us(double us) { g_wide_timeout = us > 0 ? (long long)(us * 100.0) : 1000000000ll; return SDSM_OK; }
+// Time a member of a workgroup group waits for its partners at one exchange before the group is given up (the candidate is then solved again
+// without a group: correct, one more launch).  50 ms: a partner that is not resident by then is waiting for a compute unit behind other work --
+// several processes sharing the card --, and the retry costs less than the wait (round 3 waited 10 s).
+#define SDSM_GROUP_TIMEOUT_TICKS 5000000ll
+static thread_local long long g_wide_timeout = SDSM_GROUP_TIMEOUT_TICKS;   // ticks of the 100 MHz wall clock
+extern "C" int sdsm_set_group_timeout_us(double us) { g_wide_timeout = us > 0 ? (long long)(us * 100.0) : SDSM_GROUP_TIMEOUT_TICKS; return SDSM_OK; }
+
+// Whether the caller's stream and the side streams of the last probed launch ran side by side: 1 yes, 0 they share hardware queues (the solve
+// classes of a launch then run one after the other: correct, slower -- GPU_MAX_HW_QUEUES was too small when the process first touched the GPU),
+// -1 not probed yet (no launch needed side streams so far).
+static int g_queues_distinct = -1;
+extern "C" int sdsm_side_queues_distinct(void) { return g_queues_distinct; }
+extern "C" hipError_t sdsm_launch_queue_probe(int32_t *d_words, hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream_t s3);
+// Once per device (first launch that needs the side streams): four one-wavefront kernels, one per stream, wait for each other (<= 2 ms).
+static void probe_queues(SideSet *q, hipStream_t caller)
+{
+    if (q->queues != 0) return;
+    q->queues = -1;
+    if (hipMalloc((void **)&q->probe_words, 8) != hipSuccess) { q->probe_words = nullptr; (void)hipGetLastError(); return; }
+    int32_t res[2] = {0, 1};
+    if (hipMemsetAsync(q->probe_words, 0, 8, caller) == hipSuccess && hipStreamSynchronize(caller) == hipSuccess
+        && sdsm_launch_queue_probe(q->probe_words, caller, q->side[0], q->side[1], q->side[2]) == hipSuccess) {
+        (void)hipStreamSynchronize(q->side[0]); (void)hipStreamSynchronize(q->side[1]); (void)hipStreamSynchronize(q->side[2]); (void)hipStreamSynchronize(caller);
+        if (hipMemcpy(res, q->probe_words, 8, hipMemcpyDeviceToHost) != hipSuccess) res[1] = 1;
+    }
+    q->queues = res[1] == 0 ? 1 : -1;
+    g_queues_distinct = q->queues == 1 ? 1 : 0;
+    if (q->queues != 1) {
+        const char *v = getenv("GPU_MAX_HW_QUEUES");
+        fprintf(stderr, "superdsm_amd: the streams of a launch share hardware queues (GPU_MAX_HW_QUEUES=%s): its solve classes run one after the other -- "
+                        "correct, slower.  Set GPU_MAX_HW_QUEUES=8 (or import superdsm_amd) before the process first touches the GPU.\n", v ? v : "unset: 4");
+    }
+}
 // Diagnostic builds (-DSDSM_PROFILE): device buffer of 8 int64 cycle counters per candidate, see DESIGN.md.
 extern "C" int sdsm_set_debug_buffer(void *d_buf) { g_prof = (long long *)d_buf; return SDSM_OK; }
 
@@ -599,6 +629,7 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
     if (p->n_order_c > 0 || p->n_order_d > 0 || p->n_order_w > 0) {
         if ((e = acquire_sides(p)) != hipSuccess) return hipfail(e, "side streams");
         s1 = p->sides->side[0]; s2 = p->sides->side[1]; s3 = p->sides->side[2]; fj = p->sides->fj;
+        if (p->sides->queues == 0) { std::lock_guard<std::mutex> lock(p->sides->enqueue); probe_queues(p->sides, s); }
     }
     {
         std::unique_lock<std::mutex> enq;

@@ -1846,8 +1846,8 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
     }
 }
 
-// The kernels.  LIST < 0: workgroup b takes entry b of the launch list P.order (class 1: all candidates, largest first; the workgroup
-// groups: their members, by ticket).  LIST >= 0 (the classes beyond 1): a bounded number of RESIDENT workgroups pop entries of the
+// The kernels.  Workgroup groups: workgroup b takes entry `ticket` of the launch list P.order (their members).  Everybody else (list 4: class 1, all
+// candidates, largest first; lists 0 .. 3: the classes beyond 1): a bounded number of RESIDENT workgroups pop entries of the
 // launch list (head counter BatchParams.cls_count[LIST]) until it is exhausted and solve the candidates that belong to their class.
 // The host knows only an upper bound of M, so the lists of these classes are upper bounds -- candidates that COULD belong, largest
 // first; most do not.  One workgroup per entry meant thousands of 512-thread workgroups that exit at once but each need a whole free
@@ -1863,8 +1863,11 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int h
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x;
     load_log_table(tid);
-    if constexpr (CLS != SDSM_CLS_1 && !WIDE) {              // (class 1 and the groups always take entry b: no second copy of the solver in their kernels)
-      if (list >= 0) {
+    if constexpr (!WIDE) {                                   // (one call site of the solver per kernel: the groups take entry `ticket`, everybody else pops)
+        // Class 1 too (round 4): with one workgroup per candidate the hardware deals workgroup b to compute-unit die b mod 8 IN ORDER -- a die whose
+        // candidates take longer holds up the dispatch for all eight, and the launch ended with half of the chip idle (8 different BBBC039-like
+        // images: 494 of 1024 workgroup slots in use 1.3 ms before the end, the last thousand candidates trickled in at 0.6 per microsecond).
+        // Resident workgroups that pop the next candidate balance the dies by themselves.
         int *sh = reinterpret_cast<int *>(SD + L::FLAG);
         for (;;) {
             __syncthreads();                                     // (the previous candidate is finished by all threads)
@@ -1874,21 +1877,19 @@ __global__ __launch_bounds__(WGSIZE, WPE) void sdsm_k_solve(BatchParams P, int h
             if (i >= P.n) return;
             const int ci = uni(P.order[i]);
             __syncthreads();
-            solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, false, CLS>(P, ci, 0, 0, false, records, masks, xi_out);
+            solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, false, CLS>(P, ci, 0, handles_rest, false, records, masks, xi_out);
         }
-      }
     }
-    int slot = blockIdx.x;
-    if (WIDE) {                                              // members are claimed in start order, not by workgroup index (see wide_barrier)
+    if constexpr (WIDE) {                                    // members are claimed in start order, not by workgroup index (see wide_barrier)
         int *tk = reinterpret_cast<int *>(SD + L::FLAG);
         if (tid == 0) *tk = __hip_atomic_fetch_add(P.wide_ticket + (CLS == SDSM_CLS_WIDE2B ? 1 : 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        slot = uni(*tk);
+        const int slot = uni(*tk);
         __syncthreads();
         if (slot >= P.n) return;                             // cannot happen: one ticket per workgroup of the launch
+        const int entry = uni(P.order[slot]);
+        solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, true, CLS>(P, entry & 0xffffff, (entry >> 24) & 0xff, handles_rest, false, records, masks, xi_out);
     }
-    const int entry = uni(P.order[slot]);
-    solve_candidate<NMAX, EMAX, GLOBALH, WGSIZE, WIDE, CLS>(P, WIDE ? entry & 0xffffff : entry, WIDE ? (entry >> 24) & 0xff : 0, handles_rest, false, records, masks, xi_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2043,15 +2044,46 @@ static hipError_t launch_class(const BatchParams &P, int grid, int list, int han
 
 extern "C" hipError_t sdsm_launch_setup_rows(const BatchParams &P, hipStream_t stream, const int32_t *order_w, int n_w);
 
-// Head start of the classes beyond 1: one wavefront that waits `ticks` of the 100 MHz wall clock (see sdsm_launch_solve).
-__global__ void sdsm_k_head_start(long long ticks)
+// Gate of class 1: a 512-thread workgroup needs a whole free compute unit, and once the thousands of small workgroups of class 1 flood the
+// chip none becomes free before class 1 is through -- yet the few long candidates of the large classes ARE the end of a launch.  Class 1
+// therefore starts when the FIRST kernel of every side queue has its work in resident workgroups: one wavefront on the caller's stream polls the
+// heads of their launch lists (a head at the end of its list: every entry has been claimed by a resident workgroup) and the ticket counters
+// of the workgroup groups (all tickets drawn: every member has started), with a cap -- side queues that share a hardware queue with the
+// caller's stream (GPU_MAX_HW_QUEUES too small) cannot start before this kernel ends.  (Rounds 2-3: a fixed wait of 60 / 120 us, tuned on one
+// workload mix; the wait is now what the launch needs: tens of microseconds for short lists.)
+__global__ void sdsm_k_gate(const int32_t *cls_count, const int32_t *ticket, int l0, int n0, int l1, int n1, int l2, int n2, long long cap_ticks)
 {
     const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    for (;;) {
+        bool ok = true;
+        if (n0 > 0) ok = ok && __hip_atomic_load(l0 >= 0 ? &cls_count[l0] : &ticket[-1 - l0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n0;
+        if (n1 > 0) ok = ok && __hip_atomic_load(l1 >= 0 ? &cls_count[l1] : &ticket[-1 - l1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n1;
+        if (n2 > 0) ok = ok && __hip_atomic_load(l2 >= 0 ? &cls_count[l2] : &ticket[-1 - l2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n2;
+        if (ok || wall_clock64() - t0 > cap_ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
 }
-#ifndef SDSM_HEAD_START_US
-#define SDSM_HEAD_START_US 120      // (end of round 3, side streams at default priority: 20 us: 9.5 / 5.96 ms per step of 8 different images / 8 copies;
-#endif                              //  60: 8.2 / 5.63; 120: 8.2 / 5.37; 200: 8.1 / 5.45; 300: 8.2 / 5.52 -- the resident workgroups of the empty classes are gone by then)
+#ifndef SDSM_GATE_CAP_US
+#define SDSM_GATE_CAP_US 400
+#endif
+
+// Do the caller's stream and the three side streams run side by side?  Four one-wavefront kernels, one per stream, each waits (at most
+// `cap_ticks`) until all four have started; *timed_out is set if one gave up: some of the streams share a hardware queue.
+__global__ void sdsm_k_queue_probe(int32_t *arrived, int32_t *timed_out, long long cap_ticks)
+{
+    __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4) {
+        if (wall_clock64() - t0 > cap_ticks) { __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+extern "C" hipError_t sdsm_launch_queue_probe(int32_t *d_words /* 2, zeroed */, hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream_t s3)
+{
+    hipStream_t st[4] = {s0, s1, s2, s3};
+    for (int i = 0; i < 4; i++) hipLaunchKernelGGL(sdsm_k_queue_probe, dim3(1), dim3(64), 0, st[i], d_words, d_words + 1, 200000ll);   // cap: 2 ms
+    return hipGetLastError();
+}
 
 // Resident workgroups of the classes beyond 1 (each pops entries of its launch list until the list is exhausted).  A 512-thread
 // workgroup needs a whole free compute unit and waits for one while class 1 floods the chip: no more of them than the class can use.
@@ -2059,6 +2091,7 @@ __global__ void sdsm_k_head_start(long long ticks)
 #define SDSM_RESIDENT_2B 128        // class 2b (synthetic 4096^2: 91 candidates)
 #define SDSM_RESIDENT_3 64          // global-memory class (34 there, 23-33 ms each: none may wait for another; usually none at all)
 #define SDSM_RESIDENT_1B 512        // class 1b: two per compute unit
+#define SDSM_RESIDENT_1 1280        // class 1: four (192 threads) or three (256 threads) per compute unit + a margin that starts as slots free up
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
                                         hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */,
@@ -2117,9 +2150,17 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     // -- no candidates -- "ran" 5.4 ms, class 2b behind it started when class 1 ended, the groups took 9.7 ms instead of 4.7; stream
     // priorities change nothing).  The few long candidates of the large classes ARE the end of the launch: class 1 starts some tens of
     // microseconds after them -- their resident workgroups are in place by then, the ones without work gone again.
-    if (n_c > 0 || n_d > 0 || n_w > 0) hipLaunchKernelGGL(sdsm_k_head_start, dim3(1), dim3(64), 0, stream, (long long)SDSM_HEAD_START_US * 100);
-    if (!P.latency) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
-    else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, P.n, -1, 1, records, masks, xi_out, stream);
+    if (n_c > 0 || n_d > 0 || n_w > 0) {
+        // the first kernel of every side queue: side 1: groups of class-2b layout (ticket [1]), else the global-memory class (list 3); side 2: groups of
+        // class-2 layout (ticket [0]), else class 2 (list 1); side 3: class 1b (list 0)
+        const int l0 = n_w > 0 ? -2 : 3, c0 = n_w > 0 ? n_w : n_d;
+        const int l1 = n_w > 0 ? -1 : 1, c1 = n_w > 0 ? n_w : n_c;
+        hipLaunchKernelGGL(sdsm_k_gate, dim3(1), dim3(64), 0, stream, (const int32_t *)P.cls_count, (const int32_t *)P.wide_ticket, l0, c0, l1, c1, 0, n_c,
+                           (long long)SDSM_GATE_CAP_US * 100);
+    }
+    const int g_1 = P.n < SDSM_RESIDENT_1 ? P.n : SDSM_RESIDENT_1;
+    if (!P.latency) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream);
+    else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream);
     if (e != hipSuccess) return e;
     // join
     if ((n_d > 0 || n_w > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;

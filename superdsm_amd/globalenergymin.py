@@ -372,7 +372,7 @@ def _compute_generations(adjacencies, y_img, atoms_map, log_root_dir, pruning, d
                          speculation=None, speculation_budget=DEFAULT_SPECULATION_BUDGET):
     """Returns ``(generations, costs, cover, objects, performance)`` (globalenergymin.py:183-271).  ``solver``: stands in for
     :func:`compute_objects` (same signature) -- the lock-step driver of :meth:`GlobalEnergyMinimization.process_many`.
-    ``speculation``: generations solved ahead per batch (:class:`_Speculation`); ``None``: 1 with the GPU operator, 0 when a test
+    ``speculation``: generations solved ahead per batch (:class:`_Speculation`); ``None``: DEFAULT_SPECULATION (8) with the GPU operator, 0 when a test
     substitutes it or per-candidate log files are written (their names count within the reference's batches)."""
     out = get_output(out)
     solve = solver or compute_objects
