@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of each CPU baseline variant')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the stage / compute_objects / preprocessing timings')
+    ap.add_argument('--no-ranks-per-gpu', action='store_true', help='skip the child runs of the stage with 1 / 2 / 4 worker processes on the card (extras)')
     ap.add_argument('--inflight', type=int, default=1, help='independent steps in flight on separate streams (1 = strictly sequential launches)')
     ap.add_argument('--images-workload-explicit', action='store_true', help='image_set mode: take --workload literally (default: bbbc039_like means the NIH3T3-like set of BASELINE.json configs[3])')
     ap.add_argument('--ranks-per-gpu', type=int, default=1, help='worker processes per GPU (image sets are host bound per process: several processes share a card; gloo moves the small results)')
@@ -197,10 +198,19 @@ def main():
     n_gpus_used = max(1, min(max(1, world // rpg), ndev)) if ndev > 0 else max(1, world // rpg)
     if args.dry_run:
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
-        shard_sizes = None
+        shard_sizes = payload = images_per_rank = None
         if world > 1:
             dist.barrier()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if args.mode == 'image_set':                              # the dealing of an image set and its one gather of per-image results
+            from superdsm_amd import dist as sdist
+            n_img = args.images if args.images else 49            # (BASELINE.json configs[3]: the NIH3T3 set has 49 images)
+            deal = sdist.deal_images(n_img, world)
+            local = [(i, f'objects of image {i}') for i in deal[rank]]
+            got = sdist.gather_objects(local, dst=0) if world > 1 else [local]
+            if rank == 0:
+                assert sorted(x for part in got for x in part) == [(i, f'objects of image {i}') for i in range(n_img)]
+            images_per_rank = [len(d) for d in deal]
         if args.mode == 'sharded':                                # the dealing of one batch and its one all-gather, on fake costs / payloads
             from superdsm_amd import dist as sdist
             costs = np.random.default_rng(5).integers(200, 20000, 1000)
@@ -214,11 +224,13 @@ def main():
                 recv.copy_(send)
             assert all(int(recv[r * pad]) == r for r in range(world))
             shard_sizes = [len(sh) for sh in shards]
+            payload = int(pad)
         if rank == 0:
             print(json.dumps({'metric': 'candidate DSM solves/sec', 'value': 0.0, 'unit': 'candidate solves/s', 'n_gpus': n_gpus_used, 'steps': args.steps,
                               'warmup': args.warmup, 'ms_per_step': float(t.item()), 'higher_is_better': True, 'scaling': 'strong' if args.mode == 'sharded' else 'weak', 'vs_baseline': None,
                               'dtype': 'f64', 'data': 'none (dry run of the rank plumbing)',
-                              'config': {'workload': 'dry-run', 'backend': backend, 'mode': args.mode, 'ranks': world, 'devices_visible': ndev, 'shard_sizes': shard_sizes}}))
+                              'config': {'workload': 'dry-run', 'backend': backend, 'mode': args.mode, 'ranks': world, 'ranks_per_gpu': rpg, 'devices_visible': ndev, 'shard_sizes': shard_sizes,
+                                         'payload_bytes_per_rank': payload, 'images_per_rank': images_per_rank}}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -315,6 +327,7 @@ def main():
                                f'subsets of size <= {args.max_size} + cluster universes',
                    'images_per_step': n_images, 'candidates_per_image': [len(sc['footprints']) for sc in scenes], 'candidates_per_step_per_gpu': len(fps),
                    'atoms_per_image': [int(sc['atoms'].max()) for sc in scenes], 'backend': backend if world > 1 else None,
+                   'candidates_per_rank': [len(fps)] * world, 'gather_payload_bytes_per_rank': int(sum(sizes[0])) if world > 1 else 0,
                    'ranks': world, 'ranks_per_gpu': rpg, 'devices_visible': ndev,
                    'median_N': int(np.median(recs['n_pixels'])), 'median_M': int(np.median(recs['n_deform'])),
                    'parallelism': f'{world} ranks ({rpg} per GPU), weak scaling: every rank solves its own images, one gather of records + masks per step (RCCL with one rank per GPU)'
@@ -481,6 +494,20 @@ def extras(args, scene, img, n_images, scenes=None):
                                              fp64_vector_instructions_per_pixel=ops, frac_of_fp64_vector_issue_39_3T=ops * px / (ms * 1e-3) / 39.3e12,
                                              bound='fp64 vector issue (unfused SciPy-order sums), not HBM')
     ex['preprocess'] = pre
+    # (4) the deployment DESIGN section 6 recommends for the stage (it is host bound per process): R worker processes share the card, 8 different
+    # BBBC039-like images each, one gather of the results -- measured by FRESH child processes of this run (`--mode image_set --ranks-per-gpu R`)
+    if args.workload == 'bbbc039_like' and not args.no_ranks_per_gpu:
+        for R in (1, 2, 4):
+            try:
+                res = subprocess.run([sys.executable, os.path.abspath(__file__), '--mode', 'image_set', '--workload', 'bbbc039_like', '--images-workload-explicit',
+                                      '--images', '8', '--gpus', '1', '--ranks-per-gpu', str(R), '--repeats', '3'], capture_output=True, timeout=240,
+                                     env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')})
+                line = [l for l in res.stdout.decode().splitlines() if l.startswith('{')][-1]
+                d = json.loads(line)
+                ex[f'stage_wall_ms_per_image_ranks_per_gpu_{R}'] = d['config']['wall_ms_per_image']
+                ex[f'stage_candidate_solves_per_s_ranks_per_gpu_{R}'] = d['value']
+            except Exception as e:                              # noqa: BLE001 -- an extra, not the headline
+                ex[f'stage_wall_ms_per_image_ranks_per_gpu_{R}'] = f'failed: {type(e).__name__}'
     return ex
 
 
@@ -616,13 +643,17 @@ def image_set_mode(args, world, rank, backend, n_gpus_used):
     from superdsm_amd import dist as sdist
     wl = args.workload if args.workload != 'bbbc039_like' or args.images_workload_explicit else 'nih3t3_like'
     scene = testing.make_scene(wl, max_size=2 if wl != 'bbbc039_like' else 3)
+    # BBBC039-like sets: DIFFERENT images (the eight layouts of the headline step), else copies of one scene with scaled intensities
+    scenes = [testing.make_scene(wl, max_size=3, layout_index=k) for k in range(8)] if wl == 'bbbc039_like' else [scene]
     n_images = (args.images or 4) * world
     mine = sdist.deal_images(n_images, world)[rank]
     beta = {'nih3t3_like': 1200.0, 'gowt1_like': 1188.0}.get(wl, 150.0)
     stage = globalenergymin.GlobalEnergyMinimization()
     cfg = config.Config({'global-energy-minimization': {'beta': beta, 'pruning': 'isbi24'}})
-    mk = lambda i: dict(y=np.ascontiguousarray(scene['y'] * (1 - 0.003 * (i % 7))), y_mask=np.ones(scene['y'].shape, bool), atoms=scene['atoms'],
-                        adjacencies=scene['adjacencies'], dsm_cfg=scene['dsm_cfg'])
+    def mk(i):
+        sc = scenes[i % len(scenes)]
+        return dict(y=np.ascontiguousarray(sc['y'] * (1 - 0.003 * (i % 7))) if len(scenes) == 1 else sc['y'], y_mask=np.ones(sc['y'].shape, bool), atoms=sc['atoms'],
+                    adjacencies=sc['adjacencies'], dsm_cfg=sc['dsm_cfg'])
     stage.process_many([mk(i) for i in mine[:1]], cfg, out='muted')            # warm-up: one image
     torch.cuda.synchronize()
     times = []

@@ -129,6 +129,7 @@ struct sdsm_plan {
     std::vector<int32_t> fp_labels, order;     // order: all candidates (largest first), then those whose bound on M admits more than solve class 1, then more than class 2
     int n_order_c = 0, n_order_d = 0, n_order_w = 0;   // the last list: (candidate | member << 24) of the workgroup groups
     int n_order_r = 0;                                  // then: (candidate | member << 24) of sdsm_k_setup_rows
+    int rows_mcap = 1;                                  // largest bound on M among them
     int n_setup_small = 0, n_setup_big = 0, max_label = 1;   // setup in two launches (plans that mix small and large regions): lists behind the others
     int setup_class = 2;         // LDS limits of the setup kernel that hold this plan (sdsm_setup_class)
     int mode = 0;                // sdsm_plan_set_latency_mode: 0 throughput, 1 latency, 2 no workgroup groups
@@ -254,9 +255,11 @@ static void layout_plan(sdsm_plan *p)
         if (const char *e = getenv("SDSM_K1_PIXDIV")) { const long long v = atoll(e); if (v > 0) div = v; else if (v < 0) div = 0; }   // diagnostic knob (negative: no bound)
         p->boost_pixels = div > 0 ? (int)std::min<long long>(INT_MAX, std::max<long long>(SDSM_WIDE_PIXELS, all_pixels / div)) : INT_MAX;
     }
+    long wide_slice = SDSM_WIDE_SLICE;
+    if (const char *e = getenv("SDSM_WIDE_SLICE")) { const long v = atol(e); if (v > 0) wide_slice = v; }                // diagnostic knob
     auto group_size = [&](long N) -> long {              // members of the group a region of N pixels would get (0: none)
         if (!groups || n >= (1 << 24)) return 0;
-        if (N > wide_thr) return std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (N + SDSM_WIDE_SLICE - 1) / SDSM_WIDE_SLICE));
+        if (N > wide_thr) return std::min<long>(SDSM_WIDE_MAX_G, std::max<long>(2, (N + wide_slice - 1) / wide_slice));
         if (latency && N > SDSM_WIDE_PIXELS) return std::min<long>(SDSM_LAT_GMAX, std::max<long>(2, (N + SDSM_LAT_SLICE - 1) / SDSM_LAT_SLICE));   // latency mode: the largest regions of an ordinary image too
         return 0;
     };
@@ -293,6 +296,7 @@ static void layout_plan(sdsm_plan *p)
         else c.wide_off = -1;
     }
     p->n_order_c = p->n_order_d = p->n_order_w = p->n_order_r = 0;
+    p->rows_mcap = 1;
     p->order.resize(n);
     std::iota(p->order.begin(), p->order.end(), 0);
     std::stable_sort(p->order.begin(), p->order.end(), [&](int a, int b) { return p->cand[a].N > p->cand[b].N; });
@@ -307,6 +311,7 @@ static void layout_plan(sdsm_plan *p)
     for (int k = 0; k < n; k++) {
         const int ci = p->order[k];
         for (int g = 0; g < p->cand[ci].rows_g; g++) { p->order.push_back(ci | (g << 24)); p->n_order_r++; }
+        if (p->cand[ci].rows_g > 0) p->rows_mcap = std::max(p->rows_mcap, (int)std::min<int64_t>(p->cand[ci].Mcap, SDSM_MAX_N_GLOBAL));
     }
     // Setup: a plan whose largest region needs the large tables of the setup kernel (1024 threads per candidate) but whose candidates are
     // mostly small (an image set with a few big clusters) sets the small ones up with the 256-thread class in a launch of its own
@@ -416,7 +421,7 @@ extern "C" sdsm_plan *sdsm_plan_create_multi(int n_images, const int32_t *H, con
         c.xi_off = p->total_xi; p->total_xi += c.Mcap;
         c.mask_off = p->total_mask_words; p->total_mask_words += ((int64_t)c.h * c.w + 31) / 32;
         if (6 + c.Mcap > SDSM_ENV_DENSE_N) {
-            const int64_t nn = 6 + std::min<int64_t>(c.Mcap, SDSM_MAX_N_SOLVE - 6);
+            const int64_t nn = 6 + std::min<int64_t>(c.Mcap, SDSM_MAX_N_GLOBAL - 6);
             c.hglob_off = p->n_hglob; p->n_hglob += nn * (nn + 1) / 2;
         } else c.hglob_off = -1;
         c.perm_inv = perm_inverse((uint32_t)std::max<long>(N, 1));
@@ -560,7 +565,7 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
     P.n = p->n; P.n_total = p->n; P.latency = p->mode == 1; P.n_images = (int)p->images.size();
     for (size_t i = 0; i < p->images.size(); i++) { P.img[i].H = p->images[i].H; P.img[i].W = p->images[i].W; }   // device pointers: filled by the launch
     P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.zcap_run = p->zcap_run; P.zshift = p->zshift; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
-    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels; P.boost_pixels = p->boost_pixels;
+    P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels; P.boost_pixels = p->boost_pixels; P.rows_mcap = p->rows_mcap; P.pad2 = 0;
     P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
     P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);
     P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);

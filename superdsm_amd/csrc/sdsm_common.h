@@ -64,7 +64,9 @@ typedef const u16x4 SDSM_GLOBAL *g_cu16x4_p;
 #define SDSM_ROWS_MAX_G 48
 #endif
 #define SDSM_SETUP_SMALL_PIXELS 4096   // two-launch setup: regions of at most this many pixels (that fit its tables) are set up by the 256-thread class
-#define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the largest solve class (Hessian + factor in global memory)
+#define SDSM_MAX_N_SOLVE 1024      // 6 + M handled by the LDS classes and the workgroup groups
+#define SDSM_MAX_N_GLOBAL 2048     // 6 + M handled by the global-memory class (vectors of that many unknowns in LDS, Hessian + factor in global memory): every grid the
+                                   //   setup kernel can build (SDSM_MAX_GRID points) has a DSM solve; beyond (and regions beyond the setup tables): the elliptical result, flagged
 
 #ifdef SDSM_PROFILE
 #define PROF_NOW() ((long long)__builtin_readcyclecounter())
@@ -137,6 +139,7 @@ struct BatchParams {
     double scale, epsilon, alpha;
     float hess_thr;                    // Hessian ignores row entries < hess_thr * row maximum (solver approximation)
     int32_t boost_pixels;              // throughput mode: regions with more pixels run their passes over the pixels at a raised issue priority (the long chains of a launch; layout_plan)
+    int32_t rows_mcap, pad2;           // largest bound on M among the regions whose rows sdsm_k_setup_rows builds (sizes its LDS tables)
     const CandDesc *cand;
     CandState *state;
     const int32_t *fp_labels;
@@ -184,7 +187,7 @@ __host__ __device__ __forceinline__ int sdsm_solve_class(int status, int M, int 
 {
     if (status != ST_OK) return SDSM_CLS_NONE;
     int Mfull = M;
-    if (6 + Mfull > SDSM_MAX_N_SOLVE) Mfull = 0;                             // elliptical result only (flagged unsupported)
+    if (6 + Mfull > SDSM_MAX_N_GLOBAL) Mfull = 0;                            // elliptical result only (flagged unsupported)
     const int nfull = 6 + Mfull, efull = Mfull > 0 ? env_size : 21;
     if (wide_g > 0 && nfull <= SDSM_MAX_N_SOLVE && efull <= SDSM_K2_EMAX) return SDSM_CLS_WIDE;
     if (wide_g > 0 && nfull <= SDSM_K2B_NMAX && efull <= SDSM_K2B_EMAX) return SDSM_CLS_WIDE2B;      // groups with the LDS layout of class 2b

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __shared__ int sh_M, sh_npos, sh_nneg, sh_err, sh_yhi;
     __shared__ int cls_cnt[SDSM_MAX_ELL_GROUPS + 1], cls_start[SDSM_MAX_ELL_GROUPS + 1], cls_run[SDSM_MAX_ELL_GROUPS + 1];
     __shared__ int wave_cnt[(T::WG / 64)][SDSM_MAX_ELL_GROUPS + 1];
-    __shared__ int efirst[T::GRID < SDSM_MAX_N_SOLVE ? T::GRID : SDSM_MAX_N_SOLVE];   // envelope of the solver's Hessian: first coupled column per grid point
+    __shared__ int efirst[T::GRID < SDSM_MAX_N_GLOBAL ? T::GRID : SDSM_MAX_N_GLOBAL];   // envelope of the solver's Hessian: first coupled column per grid point
 
 #ifdef SDSM_PROFILE
     long long sp_t = PROF_NOW(), sp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -336,11 +336,14 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
 
     if (blockIdx.x == 0 && tid == 0) *P.wide_ticket = 0;
     if (cd.rows_g > 0 && tid < 2 * SDSM_WIDE_SYNC) reinterpret_cast<int *>(P.wide_pool + cd.wide_off)[tid] = 0;   // counters of sdsm_k_setup_rows and of the workgroup group
-    // (a G~ block of 4 GB and more: the solve kernels address a candidate's entries by 32-bit byte offsets)
-    if (cd.h > T::DIM || cd.w > T::DIM || cd.N <= 0 || (long long)cd.NRcap * P.zcap_run >= (1ll << 28)) {
-        if (tid == 0) { CandState s = {}; s.status = cd.N <= 0 ? ST_ERROR : ST_UNSUPPORTED; *st = s; }
+    if (cd.N <= 0) {
+        if (tid == 0) { CandState s = {}; s.status = ST_ERROR; *st = s; }
         return;
     }
+    // A region beyond the tables of this kernel (bounding box; a G~ block of 4 GB and more: the solve kernels address a candidate's entries by
+    // 32-bit byte offsets) gets its packed crop and the ELLIPTICAL model only -- flagged unsupported by the solve kernel, a fallback result
+    // for the caller as after a failed DSM solve of the reference (objects.py:399-410), never an abort of the batch.
+    const bool fits = cd.h <= T::DIM && cd.w <= T::DIM && (long long)cd.NRcap * P.zcap_run < (1ll << 28);
     for (int i = tid; i < (T::LABELS + 1) / 32; i += T::WG) fpbits[i] = 0;
     for (int i = tid; i < T::DIM / 32; i += T::WG) { rowbits[i] = 0; colbits[i] = 0; }
     if (tid < 4) mom[tid] = 0;
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
             const int rr = nruns + (int)(before2 >> 16);
             uint32_t mask = 0;
             const uint32_t q0 = (uint32_t)q;
-            atomicOr(&rowbits[r >> 5], 1u << (r & 31));
+            if (fits) atomicOr(&rowbits[r >> 5], 1u << (r & 31));
 #pragma unroll
             for (int k = 0; k < SDSM_RUN; k++) {
                 if (!flag[k]) continue;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
                     P.tmp_rc[o] = ((uint32_t)(cd.r0 + r) << 16) | (uint32_t)(cd.c0 + c);
                 }
                 q++;
-                atomicOr(&colbits[c >> 5], 1u << (c & 31));
+                if (fits) atomicOr(&colbits[c >> 5], 1u << (c & 31));
                 const int ah = __double2hiint(yv) & 0x7fffffff;
                 yhi = ah > yhi ? ah : yhi;
                 if (yv < 0) nneg++;
@@ -424,6 +427,17 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     const uint32_t B = scatter_mult((uint32_t)(NR > 0 ? NR : 1));         // (every thread: a few iterations of Euclid)
 
     SETUP_T(0);
+    if (!fits) {                                          // elliptical model only (the marker M makes the solve kernel flag the result)
+        CandState s = {};
+        s.npos = sh_npos; s.nneg = sh_nneg; s.sum_r = mom[0]; s.sum_c = mom[1]; s.sum_rr = mom[2]; s.sum_cc = mom[3];
+        { int ex = ((sh_yhi >> 20) & 0x7ff) - 1022; s.yexp = ex < -400 ? -400 : (ex > 400 ? 400 : ex); }
+        s.NR = NR;
+        if (running != cd.N || NR > cd.NRcap || NR < 1) s.status = ST_ERROR;
+        else if (s.npos == 1 && !P.no_trivial_rule) s.status = ST_TRIVIAL;
+        else { plain_runs(P, cd, NR, B, tid, T::WG); s.M = SDSM_MAX_N_GLOBAL; s.status = ST_OK; }
+        if (tid == 0) *st = s;
+        return;
+    }
     // ---- 2. compressed coordinates: delete empty rows / columns (dsm.py:185-186) ---------------
     for (int r = tid; r < cd.h; r += T::WG) {
         int cnt = 0;
@@ -442,7 +456,11 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     for (int wd = 0; wd < (cd.w + 31) / 32; wd++) wc += __popc(colbits[wd]);
     __syncthreads();
 
-    CandState s = {};
+    // (the state lives in LDS, every thread stores the same values: 26 registers less across the rest of the kernel)
+    __shared__ CandState sh_state;
+    CandState &s = sh_state;
+    if (tid < (int)(sizeof(CandState) / 4)) reinterpret_cast<int *>(&sh_state)[tid] = 0;
+    __syncthreads();
     s.hc = hc; s.wc = wc; s.npos = sh_npos; s.nneg = sh_nneg;
     s.sum_r = mom[0]; s.sum_c = mom[1]; s.sum_rr = mom[2]; s.sum_cc = mom[3];
     { int ex = ((sh_yhi >> 20) & 0x7ff) - 1022; s.yexp = ex < -400 ? -400 : (ex > 400 ? 400 : ex); }
@@ -471,7 +489,8 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
     __syncthreads();
     const int cap = cd.Mcap < T::GRID ? cd.Mcap : T::GRID;
     int M = sh_M;
-    if (M > cap) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
+    // more grid points than this kernel's table (or the host's bound) holds: the elliptical model only, flagged by the solve kernel
+    if (M > cap) { plain_runs(P, cd, NR, B, tid, T::WG); s.M = SDSM_MAX_N_GLOBAL; s.status = ST_OK; if (tid == 0) *st = s; return; }
 
     SETUP_T(1);
     // ---- 3. greedy completion of the grid (dsm.py:169-181) --------------------------------------
@@ -565,9 +584,9 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
             }
         }
     }
-    if (unsupported) { s.status = ST_UNSUPPORTED; if (tid == 0) *st = s; return; }
+    if (unsupported) { __syncthreads(); plain_runs(P, cd, NR, B, tid, T::WG); s.M = SDSM_MAX_N_GLOBAL; s.status = ST_OK; if (tid == 0) *st = s; return; }
     __syncthreads();
-    if (6 + M > SDSM_MAX_N_SOLVE) {                      // the solve kernel only computes the elliptical model (flagged unsupported)
+    if (6 + M > SDSM_MAX_N_GLOBAL) {                     // the solve kernel only computes the elliptical model (flagged unsupported)
         plain_runs(P, cd, NR, B, tid, T::WG);
         s.M = M; s.status = ST_OK;
         if (tid == 0) *st = s;
@@ -732,10 +751,11 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
 // builds the envelope and completes the state.
 __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
 {
-    __shared__ uint32_t gridkeys[SDSM_MAX_N_SOLVE];
+    extern __shared__ __align__(16) unsigned char rows_dyn[];            // gridkeys[P.rows_mcap] | efirst[P.rows_mcap]: sized by the plan (launch)
+    uint32_t *gridkeys = reinterpret_cast<uint32_t *>(rows_dyn);
+    int *efirst = reinterpret_cast<int *>(rows_dyn) + P.rows_mcap;
     __shared__ uint16_t growstart[SDSM_MAX_BBOX_DIM];
     __shared__ float psf_tab[SDSM_PSF_LDS];
-    __shared__ int efirst[SDSM_MAX_N_SOLVE];
     __shared__ int scr32[SDSM_WAVES];
     __shared__ int sh_last;
     const int tid = threadIdx.x;
@@ -823,6 +843,6 @@ extern "C" hipError_t sdsm_launch_setup_rows(const BatchParams &P, hipStream_t s
     if (n_w <= 0) return hipSuccess;
     BatchParams Pw = P;
     Pw.order = order_w; Pw.n = n_w;                      // (candidate | member << 24) of the workgroup groups
-    hipLaunchKernelGGL(sdsm_k_setup_rows, dim3(n_w), dim3(SDSM_WG), 0, stream, Pw);
+    hipLaunchKernelGGL(sdsm_k_setup_rows, dim3(n_w), dim3(SDSM_WG), (size_t)8 * (Pw.rows_mcap > 0 ? Pw.rows_mcap : 1), stream, Pw);
     return hipGetLastError();
 }

@@ -29,6 +29,7 @@
 #include "sdsm_common.h"
 #include "sdsm_logtab.h"
 #include <climits>
+#include <cstdlib>
 #include <type_traits>
 
 extern __shared__ __align__(16) unsigned char sdsm_smem[];
@@ -1603,7 +1604,7 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
     }
     int Mfull = st.M;
     bool unsupported = false;
-    if (6 + Mfull > SDSM_MAX_N_SOLVE) { unsupported = true; Mfull = 0; }     // elliptical result only (flagged)
+    if (6 + Mfull > SDSM_MAX_N_GLOBAL) { unsupported = true; Mfull = 0; }    // elliptical result only (flagged)
     const int efull = Mfull > 0 ? st.env_size : 21;
     {
         const int cls = sdsm_solve_class(st.status, st.M, st.env_size, cd.N, cd.wide_g, P.k1_pixmax);
@@ -1824,7 +1825,7 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
         if (c.wg != 0) return;                                               // member 0 writes the record
     }
 
-    if (xi_out) for (int j = opaque_tid(); j < st.M; j += L::WGS) xi_out[cd.xi_off + j] = j < Mfull ? x[6 + j] : 0;
+    if (xi_out) for (int j = opaque_tid(); j < st.M && j < cd.Mcap; j += L::WGS) xi_out[cd.xi_off + j] = j < Mfull ? x[6 + j] : 0;   // (st.M may be the marker of a region beyond the setup tables)
     if (tid == 0) {
         // local basis -> full-image-normalised theta:  u = (x0 - O0) / P0
         const Frame fr = make_frame(c, P.img[cd.image].H, P.img[cd.image].W);
@@ -1910,7 +1911,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     load_log_table(tid);
     const CandDesc cd = uniform_desc(P.cand[ci]);
     const CandState st = uniform_state(P.state[ci]);
-    if (st.status != ST_OK || st.M < 0 || 6 + st.M > SDSM_MAX_N_SOLVE) return;            // out stays NaN (filled by the host)
+    if (st.status != ST_OK || st.M < 0 || 6 + st.M > SDSM_MAX_N_GLOBAL) return;           // out stays NaN (filled by the host)
     const int M = st.M, n = 6 + M;
     const int efull = M > 0 ? st.env_size : 21;
     if (nprev > 0 && n <= nprev && efull <= eprev) return;                                 // an earlier class evaluates it
@@ -2004,8 +2005,8 @@ extern "C" hipError_t sdsm_launch_eval(const BatchParams &P, const double *param
         hipLaunchKernelGGL(kern, dim3(P.n), dim3(512), lds, stream, P, SDSM_K1_NMAX, SDSM_K1_EMAX, params, out);
     }
     {
-        auto kern = sdsm_k_eval<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, true, 512>;
-        constexpr int lds = Lay<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, true, 512>::TOTAL_BYTES;
+        auto kern = sdsm_k_eval<SDSM_MAX_N_GLOBAL, SDSM_MAX_N_GLOBAL * (SDSM_MAX_N_GLOBAL + 1) / 2, true, 512>;
+        constexpr int lds = Lay<SDSM_MAX_N_GLOBAL, SDSM_MAX_N_GLOBAL * (SDSM_MAX_N_GLOBAL + 1) / 2, true, 512>::TOTAL_BYTES;
         if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(P.n), dim3(512), lds, stream, P, SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, params, out);
     }
@@ -2124,7 +2125,7 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
         if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
         // (the groups whose envelope needs the layout of class 2b: few and short next to the global-memory class behind them)
         if (n_w > 0 && (e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, true, SDSM_CLS_WIDE2B>(Pw, n_w, -1, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-        if (n_d > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_MAX_N_SOLVE * (SDSM_MAX_N_SOLVE + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(Pd, g_3, 3, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
+        if (n_d > 0 && (e = launch_class<SDSM_MAX_N_GLOBAL, SDSM_MAX_N_GLOBAL * (SDSM_MAX_N_GLOBAL + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(Pd, g_3, 3, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if (n_d > 0 && (e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
         if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
     }
@@ -2158,7 +2159,8 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
         hipLaunchKernelGGL(sdsm_k_gate, dim3(1), dim3(64), 0, stream, (const int32_t *)P.cls_count, (const int32_t *)P.wide_ticket, l0, c0, l1, c1, 0, n_c,
                            (long long)SDSM_GATE_CAP_US * 100);
     }
-    const int g_1 = P.n < SDSM_RESIDENT_1 ? P.n : SDSM_RESIDENT_1;
+    static const int resident_1 = [] { const char *e = getenv("SDSM_RESIDENT_1"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SDSM_RESIDENT_1; }();   // (diagnostic knob)
+    const int g_1 = P.n < resident_1 ? P.n : resident_1;
     if (!P.latency) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream);
     else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream);
     if (e != hipSuccess) return e;

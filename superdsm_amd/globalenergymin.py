@@ -641,10 +641,12 @@ class GlobalEnergyMinimization(Stage):
         # a thread that wakes up may wait that long for the one that is computing -- as long as a whole batch takes on the GPU.
         # No cyclic garbage collection while the threads run: a full collection of a process that has PyTorch loaded takes tens of
         # milliseconds and stops all of them (measured: every other run of an 8-image set 6 ms per image slower).
+        toggles = os.environ.get('SDSM_LOCKSTEP_TOGGLES', '1') != '0'      # (diagnostic: measure what the two settings below are worth)
         interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(interval, 2e-4))
         collecting = gc.isenabled()
-        gc.disable()
+        if toggles:
+            sys.setswitchinterval(min(interval, 2e-4))
+            gc.disable()
         try:
             threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(datas))]
             for t in threads:
@@ -652,9 +654,10 @@ class GlobalEnergyMinimization(Stage):
             for t in threads:
                 t.join()
         finally:
-            sys.setswitchinterval(interval)
-            if collecting:
-                gc.enable()
+            if toggles:
+                sys.setswitchinterval(interval)
+                if collecting:
+                    gc.enable()
         # an image whose candidate failed (CvxprogError) fails alone, as in the reference: the others' outputs are written, then the first
         # failure is raised (its ``image_index`` says which image)
         for data, prod, e in zip(datas, produced, errors):

@@ -206,3 +206,116 @@ def test_bench_sharded_mode_deals_one_batch_and_gathers_once():
     assert out['scaling'] == 'strong' and out['config']['mode'] == 'sharded' and out['config']['ranks'] == 2
     assert sum(out['config']['shard_sizes']) == 1000 and max(out['config']['shard_sizes']) - min(out['config']['shard_sizes']) <= 1
     assert out['config']['devices_visible'] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 4: more ranks than the one box ever has GPUs -- the first real 1 -> 8 run should hold no surprise in the plumbing
+# ---------------------------------------------------------------------------------------------------------
+def _bench_dry(*flags, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--dry-run'] + list(flags), env=env, capture_output=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_sharded_dry_run_world_4_and_8():
+    """`--mode sharded --dry-run` with 4 and 8 self-started ranks (gloo): n_gpus, backend, the shards of the one batch (complete, balanced
+    to one candidate), the payload every rank contributes to the one all-gather."""
+    for world in (4, 8):
+        out = _bench_dry('--gpus', str(world), '--mode', 'sharded')
+        cfg = out['config']
+        assert out['n_gpus'] == world and out['scaling'] == 'strong' and cfg['backend'] == 'gloo' and cfg['ranks'] == world
+        assert sum(cfg['shard_sizes']) == 1000 and max(cfg['shard_sizes']) - min(cfg['shard_sizes']) <= 1 and len(cfg['shard_sizes']) == world
+        assert cfg['payload_bytes_per_rank'] == 128 * max(cfg['shard_sizes'])
+        assert out['ms_per_step'] == float(world)                                  # MAX over the ranks' (1 + rank)
+
+
+def test_bench_image_set_dry_run_deals_unevenly_and_leaves_ranks_empty():
+    """`--mode image_set --dry-run`: 49 images over 8 ranks (7 / 6 per rank), 5 images over 8 ranks (three ranks get none), one gather of
+    the per-image results at the end."""
+    out = _bench_dry('--gpus', '8', '--mode', 'image_set')
+    assert out['config']['images_per_rank'] == [7, 6, 6, 6, 6, 6, 6, 6] and out['n_gpus'] == 8 and out['config']['backend'] == 'gloo'
+    out = _bench_dry('--gpus', '8', '--mode', 'image_set', '--images', '5')
+    assert out['config']['images_per_rank'] == [1, 1, 1, 1, 1, 0, 0, 0]
+    out = _bench_dry('--gpus', '4', '--ranks-per-gpu', '2', '--mode', 'image_set', '--images', '9')
+    assert out['n_gpus'] == 4 and out['config']['ranks'] == 8 and out['config']['ranks_per_gpu'] == 2 and sum(out['config']['images_per_rank']) == 9
+
+
+_GIVEN_UP_CALLS = {}
+
+
+def _solve_local_with_a_given_up_group(image, footprints, cfg, mask_info):
+    """The fake engine; rank 1's first answer reports one of its candidates as SDSM_CAND_GIVEN_UP and solves it again before returning --
+    what _gpu_solve_local does with a workgroup group that was given up on an oversubscribed card (the retry is rank-local: before the gather)."""
+    from superdsm_amd import _capi
+    rec_t, mask_t = _fake_solve_local(image, footprints, cfg, mask_info)
+    if dist.get_rank() == 1 and len(footprints) > 0 and not _GIVEN_UP_CALLS.get('done'):
+        _GIVEN_UP_CALLS['done'] = True
+        rec = rec_t.numpy().view(_capi.RECORD_DTYPE)
+        good = rec[0].copy()
+        rec['status'][0] = _capi.CAND_GIVEN_UP                    # first attempt
+        rec['energy'][0] = np.nan
+        again = np.flatnonzero(rec['status'] == _capi.CAND_GIVEN_UP)
+        sub_rec, _ = _fake_solve_local(image, [footprints[i] for i in again], cfg, mask_info[again])
+        rec[again] = sub_rec.numpy().view(_capi.RECORD_DTYPE)     # second attempt, same rank
+        assert rec[0].tobytes() == good.tobytes()
+    return rec_t, mask_t
+
+
+def _shard_worker_many(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from superdsm_amd import _capi, engine
+    img = _FakeImage()
+    ok = True
+    # 19 candidates over 4 ranks (uneven), 3 candidates over 4 ranks (an empty shard), 0 candidates
+    for fps in ([[a] for a in range(1, 12)] + [[a, a + 1] for a in range(1, 8)] + [[2, 3, 4]], [[1], [2, 3], [4]], []):
+        sh = sdist.Sharder(device='cpu', solve_local=_solve_local_with_a_given_up_group)
+        if len(fps) == 0:
+            continue                                               # (an empty batch is not sent to the engine: objects.compute_objects returns at once)
+        sb = sh.prepare(img, fps, _CFG)
+        assert sorted(np.concatenate(sb.shards).tolist()) == list(range(len(fps)))
+        if len(fps) < world:
+            assert min(len(s) for s in sb.shards) == 0
+        calls = []
+        real_gather = dist.all_gather
+        dist.all_gather = lambda *a, **k: calls.append(1) or real_gather(*a, **k)
+        sb.step()
+        dist.all_gather = real_gather
+        recs, frags = sb.results()
+        info = engine.plan_mask_boxes(img, fps, _CFG)
+        solo_rec, solo_masks = _fake_solve_local(img, fps, _CFG, info)
+        solo = solo_rec.numpy().view(_capi.RECORD_DTYPE)
+        words = (info[:, 2].astype(np.int64) * info[:, 3] + 31) // 32
+        off = np.concatenate([[0], np.cumsum(4 * words)[:-1]]).astype(np.int64)
+        solo_frags = sdist.fragments_from_masks(solo, info, off, solo_masks.numpy())
+        ok &= recs.tobytes() == solo.tobytes() and len(calls) == 1 and (recs['status'] != _capi.CAND_GIVEN_UP).all()
+        for a, b in zip(frags, solo_frags):
+            ok &= np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_batch_world4_uneven_and_empty_shards_and_a_given_up_retry():
+    """Four ranks (gloo): 19 candidates (shards of 5 / 5 / 5 / 4), 3 candidates (one rank's shard is empty), a rank whose first local
+    answer held a given-up workgroup group (solved again on that rank before the gather): every rank ends with the bytes of the unsharded
+    batch after exactly one collective."""
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker_many, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = dict(q.get() for _ in range(4))
+    assert got == {0: True, 1: True, 2: True, 3: True}

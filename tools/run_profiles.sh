@@ -5,7 +5,7 @@
 # build, the bench lines).  Outputs under gpurun_out/<tag>_*; summaries are made afterwards, off the box, by
 # tools/summarize_profiles.py <tag> and tools/kernel_timeline.py <tag>.
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --no-cpu --no-extras --steps 6 --warmup 2 --repeats 2 --min-gpu-seconds 0"
 rm -rf gpurun_out/${tag}_trace gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_sq gpurun_out/${tag}_gowt1_* gpurun_out/${tag}_s4096_*

@@ -52,13 +52,14 @@ def source_hash():
 out = dict(
     source_hash=source_hash(), workload=workload, images_per_launch=images,
     note=('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --no-cpu --no-extras --steps 6 --warmup 2 --repeats 2`.  Counters are in KB.  '
-          'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a WIDE (16 B/lane) coalesced stream; this kernel '
-          'reads 2-8 B per lane (u16 / f32 / f64), a width the guide lists as uncalibrated, so the raw value is kept and the '
-          'x2 figure is given as an upper bound.'),
+          'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a WIDE (16 B/lane) coalesced stream.  The bulk of what the solve '
+          'kernels read is such a stream (the 16-byte weights of the run entries, global_load_dwordx4 at consecutive lanes; beside it the 16-byte halves of the '
+          'packed crop and 4-byte index words): the reported traffic is 2 x FETCH_SIZE + WRITE_SIZE (since round 4; rounds 1-3 reported the raw counter, '
+          'a lower bound); the raw value is kept beside it.'),
     fetch=fetch, write=write,
     solve_fetch_bytes_per_launch_raw=solve_fetch, solve_fetch_bytes_per_launch_x2=2 * solve_fetch,
     solve_write_bytes_per_launch=solve_write,
-    solve_hbm_bytes_per_launch=solve_fetch + solve_write)
+    solve_hbm_bytes_per_launch=2 * solve_fetch + solve_write, solve_hbm_bytes_per_launch_raw=solve_fetch + solve_write)
 sq = {}
 files = glob.glob(os.path.join(root, 'gpurun_out', f'{tag}_sq', '*', '*counter_collection.csv'))
 if files:
