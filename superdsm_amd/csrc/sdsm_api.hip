@@ -566,7 +566,7 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
     for (size_t i = 0; i < p->images.size(); i++) { P.img[i].H = p->images[i].H; P.img[i].W = p->images[i].W; }   // device pointers: filled by the launch
     P.k = p->k; P.R = p->R; P.subsample = p->cfg.smooth_subsample; P.zcap = p->zcap; P.zcap_run = p->zcap_run; P.zshift = p->zshift; P.no_deform = p->no_deform; P.no_trivial_rule = p->cfg.flags & 1;
     P.init_elliptical = p->cfg.init_elliptical; P.max_iters = p->cfg.max_iters; P.k1_pixmax = p->wide_pixels; P.boost_pixels = p->boost_pixels; P.rows_mcap = p->rows_mcap; P.pad2 = 0;
-    P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha;
+    P.scale = p->cfg.scale; P.epsilon = p->cfg.epsilon; P.alpha = p->cfg.alpha; P.reg_unit = p->cfg.alpha * std::sqrt(p->cfg.epsilon);
     P.cand = (const CandDesc *)(b + p->off_cand); P.state = (CandState *)(b + p->off_state);
     P.fp_labels = (const int32_t *)(b + p->off_fp); P.order = (const int32_t *)(b + p->off_order);
     P.crop_y = (double *)(b + p->off_crop_y); P.crop_rc = (uint32_t *)(b + p->off_crop_rc); P.crop_cc = (uint32_t *)(b + p->off_crop_cc);

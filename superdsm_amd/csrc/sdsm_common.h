@@ -137,6 +137,7 @@ struct BatchParams {
     int32_t init_elliptical, max_iters;
     int32_t k1_pixmax;                 // regions with more pixels are solved by the 512-thread classes (layout_plan: a fixed bound in latency mode, relative to the plan's pixels in throughput mode)
     double scale, epsilon, alpha;
+    double reg_unit;                   // alpha * sqrt(epsilon): the regulariser's value per grid point at xi = 0 (dsm.py:325-326), computed on the host
     float hess_thr;                    // Hessian ignores row entries < hess_thr * row maximum (solver approximation)
     int32_t boost_pixels;              // throughput mode: regions with more pixels run their passes over the pixels at a raised issue priority (the long chains of a launch; layout_plan)
     int32_t rows_mcap, pad2;           // largest bound on M among the regions whose rows sdsm_k_setup_rows builds (sizes its LDS tables)

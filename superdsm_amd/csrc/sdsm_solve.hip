@@ -1635,7 +1635,7 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
     c.ell_im = (g_cu32_p)(P.ell_im + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(reinterpret_cast<const f32x4 *>(P.ell_w) + cd.ell_off);
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
     c.scale = P.scale / cd.N;                                   // objects.py:380
-    c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * Mfull;   // (only read by passes with M = Mfull > 0)
+    c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.reg_unit * Mfull;   // (only read by passes with M = Mfull > 0)
     c.yexp = st.yexp; c.boost = cd.N > P.boost_pixels;
     // local frame: centre of the bounding box, half extents
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(WGSIZE) void sdsm_k_eval(BatchParams P, int nprev, 
     c.aux = (g_cu32_p)(P.run_aux + cd.run_off);
     c.ell_im = (g_cu32_p)(P.ell_im + cd.ell_off); c.ell_w4 = (g_cf32x4_p)(reinterpret_cast<const f32x4 *>(P.ell_w) + cd.ell_off);
     c.hglob = (GLOBALH && cd.hglob_off >= 0) ? P.hglob + cd.hglob_off : nullptr;
-    c.scale = P.scale / cd.N; c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.alpha * sqrt(P.epsilon) * M;
+    c.scale = P.scale / cd.N; c.epsilon = P.epsilon; c.alpha = P.alpha; c.reg0 = P.reg_unit * M;
     c.yexp = st.yexp; c.boost = 0;
     const double half_r = 0.5 * (cd.h - 1), half_c = 0.5 * (cd.w - 1);
     c.rmid = cd.r0 + half_r; c.cmid = cd.c0 + half_c;
