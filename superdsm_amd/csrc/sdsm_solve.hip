@@ -2052,20 +2052,32 @@ extern "C" hipError_t sdsm_launch_setup_rows(const BatchParams &P, hipStream_t s
 // of the workgroup groups (all tickets drawn: every member has started), with a cap -- side queues that share a hardware queue with the
 // caller's stream (GPU_MAX_HW_QUEUES too small) cannot start before this kernel ends.  (Rounds 2-3: a fixed wait of 60 / 120 us, tuned on one
 // workload mix; the wait is now what the launch needs: tens of microseconds for short lists.)
-__global__ void sdsm_k_gate(const int32_t *cls_count, const int32_t *ticket, int l0, int n0, int l1, int n1, int l2, int n2, long long cap_ticks)
+__global__ void sdsm_k_gate(const int32_t *cls_count, const int32_t *ticket, int l0, int n0, int l1, int n1, int l2, int n2, long long cap_ticks, long long stall_ticks)
 {
     const long long t0 = wall_clock64();
+    long long t_change = t0;
+    int last = 0;
     for (;;) {
-        bool ok = true;
-        if (n0 > 0) ok = ok && __hip_atomic_load(l0 >= 0 ? &cls_count[l0] : &ticket[-1 - l0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n0;
-        if (n1 > 0) ok = ok && __hip_atomic_load(l1 >= 0 ? &cls_count[l1] : &ticket[-1 - l1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n1;
-        if (n2 > 0) ok = ok && __hip_atomic_load(l2 >= 0 ? &cls_count[l2] : &ticket[-1 - l2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n2;
-        if (ok || wall_clock64() - t0 > cap_ticks) break;
+        const int c0 = n0 > 0 ? __hip_atomic_load(l0 >= 0 ? &cls_count[l0] : &ticket[-1 - l0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int c1 = n1 > 0 ? __hip_atomic_load(l1 >= 0 ? &cls_count[l1] : &ticket[-1 - l1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int c2 = n2 > 0 ? __hip_atomic_load(l2 >= 0 ? &cls_count[l2] : &ticket[-1 - l2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        if (c0 >= n0 && c1 >= n1 && c2 >= n2) break;          // every list claimed, every member started
+        const long long now = wall_clock64();
+        if (now - t0 > cap_ticks) break;
+        // ... or nothing moves any more: the resident workgroups are all busy with candidates of their own (more real candidates than resident
+        // workgroups: synthetic 4096^2), the members that fit the chip have started (more members than compute units: GOWT1-like) -- whatever can
+        // be resident is (round 4, first version without this: the gate ran into its cap on exactly those launches, 0.4-0.9 ms)
+        const int sum = c0 + c1 + c2;
+        if (sum != last) { last = sum; t_change = now; }
+        else if (sum > 0 && now - t_change > stall_ticks) break;
         __builtin_amdgcn_s_sleep(16);
     }
 }
 #ifndef SDSM_GATE_CAP_US
 #define SDSM_GATE_CAP_US 400
+#endif
+#ifndef SDSM_GATE_STALL_US
+#define SDSM_GATE_STALL_US 20
 #endif
 
 // Do the caller's stream and the three side streams run side by side?  Four one-wavefront kernels, one per stream, each waits (at most
@@ -2157,7 +2169,7 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
         const int l0 = n_w > 0 ? -2 : 3, c0 = n_w > 0 ? n_w : n_d;
         const int l1 = n_w > 0 ? -1 : 1, c1 = n_w > 0 ? n_w : n_c;
         hipLaunchKernelGGL(sdsm_k_gate, dim3(1), dim3(64), 0, stream, (const int32_t *)P.cls_count, (const int32_t *)P.wide_ticket, l0, c0, l1, c1, 0, n_c,
-                           (long long)SDSM_GATE_CAP_US * 100);
+                           (long long)SDSM_GATE_CAP_US * 100, (long long)SDSM_GATE_STALL_US * 100);
     }
     static const int resident_1 = [] { const char *e = getenv("SDSM_RESIDENT_1"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SDSM_RESIDENT_1; }();   // (diagnostic knob)
     const int g_1 = P.n < resident_1 ? P.n : resident_1;

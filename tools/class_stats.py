@@ -7,7 +7,8 @@ import torch
 from superdsm_amd import _capi, engine, testing
 wl = sys.argv[1]
 nimg = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-scenes = [testing.make_scene(wl, max_size=3, layout_index=k % 8 if wl == 'bbbc039_like' else 0) for k in range(nimg)]
+same = len(sys.argv) > 3 and sys.argv[3] == 'same'      # the step of rounds 1-2: copies of ONE image
+scenes = [testing.make_scene(wl, max_size=3, layout_index=k % 8 if wl == 'bbbc039_like' and not same else 0) for k in range(nimg)]
 fps = [fp for sc in scenes for fp in sc['footprints']]
 image_of = np.concatenate([np.full(len(sc['footprints']), k, np.int32) for k, sc in enumerate(scenes)])
 imgs = [engine.DeviceImage(sc['y'], None, sc['atoms'], sc['dsm_cfg']['background_margin']) for sc in scenes]

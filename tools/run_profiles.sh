@@ -6,8 +6,10 @@
 # tools/summarize_profiles.py <tag> and tools/kernel_timeline.py <tag>.
 set -e
 tag=${1:-r04}
+part=${2:-ab}     # a: the rocprofv3 passes; b: diagnostic build, multi-rank rehearsals, the bench line (two calls fit gpurun's time limit)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --no-cpu --no-extras --steps 6 --warmup 2 --repeats 2 --min-gpu-seconds 0"
+if [[ $part == *a* ]]; then
 rm -rf gpurun_out/${tag}_trace gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_sq gpurun_out/${tag}_gowt1_* gpurun_out/${tag}_s4096_*
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -- $B > gpurun_out/${tag}_p1.log 2>&1
 echo "trace done"
@@ -30,10 +32,13 @@ for wl in gowt1_like synthetic4096; do
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_${short}_write -- $W > gpurun_out/${tag}_${short}_p3.log 2>&1
     echo "$wl done"
 done
+fi
+if [[ $part == *b* ]]; then
 if [ -f superdsm_amd/libsdsm_hip_prof.so ]; then
     SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/gpu_phase_profile.py > gpurun_out/${tag}_phase.log 2>&1
     SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/class_stats.py bbbc039_like 8 > gpurun_out/${tag}_class_stats_bbbc039_8.log 2>&1
     SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/class_stats.py synthetic4096 > gpurun_out/${tag}_class_stats_s4096.log 2>&1
+    SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/class_stats.py bbbc039_like 8 same > gpurun_out/${tag}_class_stats_bbbc039_8same.log 2>&1 || true
     echo "phase done"
 fi
 python3 bench.py --mode image_set --images 3 > gpurun_out/${tag}_bench_image_set.json 2> gpurun_out/${tag}_bench_image_set.err
@@ -44,3 +49,4 @@ python3 bench.py --gpus 2 --mode sharded --steps 3 --warmup 1 > gpurun_out/${tag
 echo "sharded, 2 ranks (one card) done"
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench done"
+fi
