@@ -300,8 +300,10 @@ struct SetupLimL { static constexpr int DIM = SDSM_MAX_BBOX_DIM, GRID = SDSM_MAX
 // LDS of the setup kernel is sized by the limits T of a plan's class (SetupLimits below, chosen by the host from the plan's
 // largest bounding box, bound on M, label and PSF): the common plans -- regions of a few hundred pixels across -- then run four
 // workgroups per compute unit instead of the two that the largest tables allow (1.58 -> 1.22 ms on the 8-image launch).
+// One candidate by one workgroup (`return` leaves the candidate; every exit is uniform over the workgroup).  A function of its own: with the body written into
+// the kernel the register allocator left 2 / 6 spilled registers (12 / 20 B of scratch per lane) in two of the three instantiations, this way none.
 template <class T>
-__global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
+__device__ __forceinline__ void setup_candidate(const BatchParams &P)
 {
     static_assert((T::LABELS + 1) / 32 <= T::PSFW && T::DIM % 32 == 0, "setup limits");
     // footprint bitset during the region scan, then the PSF table (k * k floats, if it fits) for the rows of G~
@@ -743,6 +745,12 @@ __global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
 #ifdef SDSM_PROFILE
     if (P.prof2 && tid == 0) for (int k = 0; k < 8; k++) P.prof2[(size_t)ci * 8 + k] = sp_acc[k];
 #endif
+}
+
+template <class T>
+__global__ __launch_bounds__(T::WG, T::WPE) void sdsm_k_setup(BatchParams P)
+{
+    setup_candidate<T>(P);
 }
 
 // Rows of G~ and envelope of the very large regions: one workgroup per member of the region's workgroup group, each takes
