@@ -159,12 +159,17 @@ struct sdsm_plan {
 static std::mutex g_pool_mutex;
 static std::vector<SideSet *> g_side_sets;
 
-static hipError_t acquire_sides(const sdsm_plan *p)
+static hipError_t acquire_sides(const sdsm_plan *p, hipStream_t caller)
 {
-    if (p->sides) return hipSuccess;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    // the set belongs to a device: the caller's stream must live on the calling thread's current device (as PyTorch arranges it) -- a stream of another device
+    // would fork work onto side streams of the wrong card
+    int sdev = dev;
+    if (caller && hipStreamGetDevice(caller, &sdev) == hipSuccess && sdev != dev) return hipErrorInvalidDevice;
+    (void)hipGetLastError();
+    if (p->sides) return p->sides->device == dev ? hipSuccess : hipErrorInvalidDevice;   // (a plan stays with the device of its first launch)
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (SideSet *q : g_side_sets) if (q->device == dev) { p->sides = q; return hipSuccess; }
     SideSet *s = new SideSet();
@@ -632,7 +637,7 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
     hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
     hipEvent_t *fj = nullptr;
     if (p->n_order_c > 0 || p->n_order_d > 0 || p->n_order_w > 0) {
-        if ((e = acquire_sides(p)) != hipSuccess) return hipfail(e, "side streams");
+        if ((e = acquire_sides(p, s)) != hipSuccess) return hipfail(e, "side streams (the stream must belong to the current device; a plan stays with the device of its first launch)");
         s1 = p->sides->side[0]; s2 = p->sides->side[1]; s3 = p->sides->side[2]; fj = p->sides->fj;
         if (p->sides->queues == 0) { std::lock_guard<std::mutex> lock(p->sides->enqueue); probe_queues(p->sides, s); }
     }

@@ -2133,24 +2133,32 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     //   caller's stream: class 1 (all candidates in the host's order, largest first; the others leave at once).
     // The driver maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with another stream in use by the caller a side
     // stream may share a queue and wait behind its neighbour -- superdsm_amd sets the variable to 8 when it is imported first.
+    // An error while enqueueing (a launch that fails) must not leave forked work behind on the side streams, which all plans of the device share: the first error
+    // is kept, nothing further is launched, but every side stream that was forked is still recorded and joined below.
+    hipError_t first = hipSuccess;
+    auto keep = [&](hipError_t r) { if (first == hipSuccess && r != hipSuccess) first = r; return first == hipSuccess; };
+    bool forked1 = false, forked2 = false, forked3 = false;
     if (n_d > 0 || n_w > 0) {
-        if ((e = hipStreamWaitEvent(side1, ev[0], 0)) != hipSuccess) return e;
-        // (the groups whose envelope needs the layout of class 2b: few and short next to the global-memory class behind them)
-        if (n_w > 0 && (e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, true, SDSM_CLS_WIDE2B>(Pw, n_w, -1, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-        if (n_d > 0 && (e = launch_class<SDSM_MAX_N_GLOBAL, SDSM_MAX_N_GLOBAL * (SDSM_MAX_N_GLOBAL + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(Pd, g_3, 3, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-        if (n_d > 0 && (e = launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side1)) != hipSuccess) return e;
-        if ((e = hipEventRecord(ev[1], side1)) != hipSuccess) return e;
+        if (keep(hipStreamWaitEvent(side1, ev[0], 0))) {
+            forked1 = true;
+            // (the groups whose envelope needs the layout of class 2b: few and short next to the global-memory class behind them)
+            if (n_w > 0 && first == hipSuccess) keep(launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, true, SDSM_CLS_WIDE2B>(Pw, n_w, -1, 0, records, masks, xi_out, side1));
+            if (n_d > 0 && first == hipSuccess) keep(launch_class<SDSM_MAX_N_GLOBAL, SDSM_MAX_N_GLOBAL * (SDSM_MAX_N_GLOBAL + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(Pd, g_3, 3, 0, records, masks, xi_out, side1));
+            if (n_d > 0 && first == hipSuccess) keep(launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side1));
+        }
     }
-    if (n_w > 0 || n_c > 0) {
-        if ((e = hipStreamWaitEvent(side2, ev[0], 0)) != hipSuccess) return e;
-        if (n_w > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true, SDSM_CLS_WIDE>(Pw, n_w, -1, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
-        if (n_c > 0 && (e = launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, false, SDSM_CLS_2>(Pc, g_c, 1, 0, records, masks, xi_out, side2)) != hipSuccess) return e;
-        if ((e = hipEventRecord(ev[2], side2)) != hipSuccess) return e;
+    if ((n_w > 0 || n_c > 0) && first == hipSuccess) {
+        if (keep(hipStreamWaitEvent(side2, ev[0], 0))) {
+            forked2 = true;
+            if (n_w > 0 && first == hipSuccess) keep(launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, true, SDSM_CLS_WIDE>(Pw, n_w, -1, 0, records, masks, xi_out, side2));
+            if (n_c > 0 && first == hipSuccess) keep(launch_class<SDSM_MAX_N_SOLVE, SDSM_K2_EMAX, 2, false, 512, false, SDSM_CLS_2>(Pc, g_c, 1, 0, records, masks, xi_out, side2));
+        }
     }
-    if (n_c > 0) {
-        if ((e = hipStreamWaitEvent(side3, ev[0], 0)) != hipSuccess) return e;
-        if ((e = launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, SDSM_K1B_WPE, false, SDSM_K1B_THREADS, false, SDSM_CLS_1B>(Pc, g_b, 0, 0, records, masks, xi_out, side3)) != hipSuccess) return e;
-        if ((e = hipEventRecord(ev[3], side3)) != hipSuccess) return e;
+    if (n_c > 0 && first == hipSuccess) {
+        if (keep(hipStreamWaitEvent(side3, ev[0], 0))) {
+            forked3 = true;
+            keep(launch_class<SDSM_K1B_NMAX, SDSM_K1B_EMAX, SDSM_K1B_WPE, false, SDSM_K1B_THREADS, false, SDSM_CLS_1B>(Pc, g_b, 0, 0, records, masks, xi_out, side3));
+        }
     }
     // class 1 runs THREE wavefronts per SIMD (168 registers).  Measured on the 8-image launch of round 2: 7.4 ms at two wavefronts
     // (240 registers), 5.5 ms at three, 6.6 ms at four (128 registers: 36 spilled) -- the solver is latency bound and a third workgroup
@@ -2163,7 +2171,7 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     // -- no candidates -- "ran" 5.4 ms, class 2b behind it started when class 1 ended, the groups took 9.7 ms instead of 4.7; stream
     // priorities change nothing).  The few long candidates of the large classes ARE the end of the launch: class 1 starts some tens of
     // microseconds after them -- their resident workgroups are in place by then, the ones without work gone again.
-    if (n_c > 0 || n_d > 0 || n_w > 0) {
+    if ((n_c > 0 || n_d > 0 || n_w > 0) && first == hipSuccess) {
         // the first kernel of every side queue: side 1: groups of class-2b layout (ticket [1]), else the global-memory class (list 3); side 2: groups of
         // class-2 layout (ticket [0]), else class 2 (list 1); side 3: class 1b (list 0)
         const int l0 = n_w > 0 ? -2 : 3, c0 = n_w > 0 ? n_w : n_d;
@@ -2173,12 +2181,13 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     }
     static const int resident_1 = [] { const char *e = getenv("SDSM_RESIDENT_1"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SDSM_RESIDENT_1; }();   // (diagnostic knob)
     const int g_1 = P.n < resident_1 ? P.n : resident_1;
-    if (!P.latency) e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream);
-    else e = launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream);
-    if (e != hipSuccess) return e;
-    // join
-    if ((n_d > 0 || n_w > 0) && (e = hipStreamWaitEvent(stream, ev[1], 0)) != hipSuccess) return e;
-    if ((n_w > 0 || n_c > 0) && (e = hipStreamWaitEvent(stream, ev[2], 0)) != hipSuccess) return e;
-    if (n_c > 0 && (e = hipStreamWaitEvent(stream, ev[3], 0)) != hipSuccess) return e;
-    return hipSuccess;
+    if (first == hipSuccess) {
+        if (!P.latency) keep(launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream));
+        else keep(launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream));
+    }
+    // join (also after an error: whatever was forked is recorded and waited for)
+    if (forked1) { hipError_t r = hipEventRecord(ev[1], side1); if (r == hipSuccess) r = hipStreamWaitEvent(stream, ev[1], 0); keep(r); }
+    if (forked2) { hipError_t r = hipEventRecord(ev[2], side2); if (r == hipSuccess) r = hipStreamWaitEvent(stream, ev[2], 0); keep(r); }
+    if (forked3) { hipError_t r = hipEventRecord(ev[3], side3); if (r == hipSuccess) r = hipStreamWaitEvent(stream, ev[3], 0); keep(r); }
+    return first;
 }
