@@ -13,7 +13,7 @@
 #include <climits>
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out, hipStream_t stream,
-                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev, int n_c, int n_d, int n_w, int n_r);
+                                        hipStream_t side1, hipStream_t side2, hipStream_t side3, hipStream_t side4, hipEvent_t *ev, int n_c, int n_d, int n_w, int n_r);
 extern "C" hipError_t sdsm_image_prepare_impl(const double *, const uint8_t *, const int32_t *, int, int, double, int, uint8_t *, int32_t *, void *, hipStream_t);
 extern "C" hipError_t sdsm_preprocess_impl(const double *, int, int, double, double, double, int, double *, void *, hipStream_t);
 extern "C" void sdsm_gauss_kernel_host(double sigma, int radius, double *w);
@@ -119,7 +119,7 @@ struct PlanImage { int H, W, n_atoms; };
 // destroyed: creating and destroying HIP streams costs milliseconds (hipStreamDestroy synchronises), a reference-style caller
 // builds a plan per batch.  A set carries no state between users (events are recorded before they are waited for).
 #include <mutex>
-struct SideSet { hipStream_t side[3]; hipEvent_t fj[4]; int device; std::mutex enqueue; int queues = 0; int32_t *probe_words = nullptr; };   // queues: 0 not probed yet, 1 the four streams run side by side, -1 they share hardware queues
+struct SideSet { hipStream_t side[4]; hipEvent_t fj[5]; int device; std::mutex enqueue; int queues = 0; int32_t *probe_words = nullptr; };   // queues: 0 not probed yet, 1 the four streams run side by side, -1 they share hardware queues
 struct sdsm_plan {
     int n = 0;
     std::vector<PlanImage> images;             // one entry for sdsm_plan_create, several for sdsm_plan_create_multi
@@ -178,8 +178,8 @@ static hipError_t acquire_sides(const sdsm_plan *p, hipStream_t caller)
     // launch is short and costs 3 ms of the 71 of the synthetic 4096^2 launch, where every class has work: measured, round 3.  A fourth
     // side stream for class 2, beside the groups instead of behind them: 8 different BBBC039-like images 8.2 -> 8.5 ms, GOWT1-like
     // 4.9 -> 5.2: its 256 resident workgroups take compute units from the group members at the start.)
-    for (int i = 0; i < 3; i++) if ((e = hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking)) != hipSuccess) { delete s; return e; }
-    for (int i = 0; i < 4; i++) if ((e = hipEventCreateWithFlags(&s->fj[i], hipEventDisableTiming)) != hipSuccess) { delete s; return e; }
+    for (int i = 0; i < 4; i++) if ((e = hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking)) != hipSuccess) { delete s; return e; }   // (the fourth: class 2b of plans without groups)
+    for (int i = 0; i < 5; i++) if ((e = hipEventCreateWithFlags(&s->fj[i], hipEventDisableTiming)) != hipSuccess) { delete s; return e; }
     g_side_sets.push_back(s);
     p->sides = s;
     return hipSuccess;
@@ -644,7 +644,7 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
     {
         std::unique_lock<std::mutex> enq;
         if (p->sides) enq = std::unique_lock<std::mutex>(p->sides->enqueue);
-        if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, s3, fj, p->n_order_c, p->n_order_d, p->n_order_w, p->n_order_r)) != hipSuccess) return hipfail(e, "launch solve");
+        if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, s3, p->sides ? p->sides->side[3] : nullptr, fj, p->n_order_c, p->n_order_d, p->n_order_w, p->n_order_r)) != hipSuccess) return hipfail(e, "launch solve");
     }
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
     return SDSM_OK;

@@ -2107,7 +2107,7 @@ extern "C" hipError_t sdsm_launch_queue_probe(int32_t *d_words /* 2, zeroed */, 
 #define SDSM_RESIDENT_1 1280        // class 1: four (192 threads) or three (256 threads) per compute unit + a margin that starts as slots free up
 
 extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *records, uint32_t *masks, double *xi_out,
-                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipEvent_t *ev /* 4 */,
+                                        hipStream_t stream, hipStream_t side1, hipStream_t side2, hipStream_t side3, hipStream_t side4, hipEvent_t *ev /* 5 */,
                                         int n_c, int n_d, int n_w, int n_r)
 {
     hipError_t e;
@@ -2137,14 +2137,27 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     // is kept, nothing further is launched, but every side stream that was forked is still recorded and joined below.
     hipError_t first = hipSuccess;
     auto keep = [&](hipError_t r) { if (first == hipSuccess && r != hipSuccess) first = r; return first == hipSuccess; };
-    bool forked1 = false, forked2 = false, forked3 = false;
+    bool forked1 = false, forked2 = false, forked3 = false, forked4 = false;
+    // Plans WITHOUT workgroup groups (synthetic 4096^2: every class has hundreds of candidates of its own): class 2b on a queue of its own instead of behind the
+    // global-memory class -- a kernel behind another one starts when class 1 already holds the chip with resident workgroups, and a 512-thread workgroup then gets no
+    // compute unit before class 1 is through (start / end stamps of that launch: class 2b started at 50 of 59 ms and was its last 9 ms).  With groups the queues stay as
+    // they are (a fourth stream for class 2 beside the groups was measured slower in round 3: its resident workgroups take compute units from the group members).
+    // (only where the list is long: on the 8-copies step, whose list of 2b / 3 candidates holds a few dozen upper bounds and no real candidate, the 128 more resident
+    // workgroups at the start cost 0.2 of 4.9 ms)
+    const bool own_2b = n_w == 0 && n_d >= 2 * SDSM_RESIDENT_2B && side4 != nullptr;
     if (n_d > 0 || n_w > 0) {
         if (keep(hipStreamWaitEvent(side1, ev[0], 0))) {
             forked1 = true;
             // (the groups whose envelope needs the layout of class 2b: few and short next to the global-memory class behind them)
             if (n_w > 0 && first == hipSuccess) keep(launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, true, SDSM_CLS_WIDE2B>(Pw, n_w, -1, 0, records, masks, xi_out, side1));
             if (n_d > 0 && first == hipSuccess) keep(launch_class<SDSM_MAX_N_GLOBAL, SDSM_MAX_N_GLOBAL * (SDSM_MAX_N_GLOBAL + 1) / 2, 2, true, 512, false, SDSM_CLS_3>(Pd, g_3, 3, 0, records, masks, xi_out, side1));
-            if (n_d > 0 && first == hipSuccess) keep(launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side1));
+            if (n_d > 0 && !own_2b && first == hipSuccess) keep(launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side1));
+        }
+    }
+    if (own_2b && first == hipSuccess) {
+        if (keep(hipStreamWaitEvent(side4, ev[0], 0))) {
+            forked4 = true;
+            keep(launch_class<SDSM_K2B_NMAX, SDSM_K2B_EMAX, 2, false, 512, false, SDSM_CLS_2B>(Pd, g_d, 2, 0, records, masks, xi_out, side4));
         }
     }
     if ((n_w > 0 || n_c > 0) && first == hipSuccess) {
@@ -2189,5 +2202,6 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     if (forked1) { hipError_t r = hipEventRecord(ev[1], side1); if (r == hipSuccess) r = hipStreamWaitEvent(stream, ev[1], 0); keep(r); }
     if (forked2) { hipError_t r = hipEventRecord(ev[2], side2); if (r == hipSuccess) r = hipStreamWaitEvent(stream, ev[2], 0); keep(r); }
     if (forked3) { hipError_t r = hipEventRecord(ev[3], side3); if (r == hipSuccess) r = hipStreamWaitEvent(stream, ev[3], 0); keep(r); }
+    if (forked4) { hipError_t r = hipEventRecord(ev[4], side4); if (r == hipSuccess) r = hipStreamWaitEvent(stream, ev[4], 0); keep(r); }
     return first;
 }

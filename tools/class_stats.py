@@ -30,7 +30,9 @@ env = state[:, 15].astype(np.int64); n = recs['n_deform'] + 6; N = recs['n_pixel
 p = prof.cpu().numpy()[:len(fps) * 16].reshape(-1, 16).astype(float)
 tot = p[:, 5] / 2.4e6
 k1 = (n <= 128) & (env <= 2560); k1b = ~k1 & (n <= 256) & (env <= 7168); k2 = ~k1 & ~k1b & (env <= 11000); k2b = ~k1 & ~k1b & ~k2 & (n <= 512) & (env <= 15170); k3 = ~k1 & ~k1b & ~k2 & ~k2b
-grp = (N > 12288) & (env <= 11000)          # throughput mode: regions of more than 12 288 pixels whose envelope fits class 2 are solved by workgroup groups (while the member budget lasts)
+gm = np.zeros(batch.n, np.int32)
+_capi.check(_capi.lib().sdsm_plan_schedule(batch.plan, gm.ctypes.data_as(C.c_void_p), None), 'schedule')
+grp = (gm > 0) & (((n <= 1024) & (env <= 11000)) | ((n <= 512) & (env <= 15170)))     # solved by a workgroup group (the plan's own schedule, sdsm_plan_schedule, and the layouts of sdsm_solve_class)
 for nm, m in (('K1', k1 & ~grp), ('K1b', k1b & ~grp), ('K2', k2 & ~grp), ('K2b', k2b), ('K3', k3), ('groups', grp)):
     if m.any():
         print(nm, 'cands', m.sum(), 'sum ms %.1f' % tot[m].sum(), 'median ms %.2f' % np.median(tot[m]), 'max ms %.2f' % tot[m].max(), 'M median', int(np.median(recs['n_deform'][m])), 'M max', int(recs['n_deform'][m].max()),

@@ -38,6 +38,8 @@ if [ -f superdsm_amd/libsdsm_hip_prof.so ]; then
     SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/gpu_phase_profile.py > gpurun_out/${tag}_phase.log 2>&1
     SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/class_stats.py bbbc039_like 8 > gpurun_out/${tag}_class_stats_bbbc039_8.log 2>&1
     SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/class_stats.py synthetic4096 > gpurun_out/${tag}_class_stats_s4096.log 2>&1
+    SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/class_stats.py gowt1_like > gpurun_out/${tag}_class_stats_gowt1.log 2>&1 || true
+    SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/class_stats.py nih3t3_like > gpurun_out/${tag}_class_stats_nih3t3.log 2>&1 || true
     SDSM_HIP_LIB=superdsm_amd/libsdsm_hip_prof.so timeout -k 10 300 python3 tools/class_stats.py bbbc039_like 8 same > gpurun_out/${tag}_class_stats_bbbc039_8same.log 2>&1 || true
     echo "phase done"
 fi
