@@ -347,6 +347,9 @@ def main():
                      'pixel_evaluations_per_image': int((evals * recs['n_pixels']).sum() // n_images),
                      'algorithmic_bytes_definition': 'SURVEY.md 8(d): sum over candidates of E_c (12 N_c + 8 (6 + M_c)) + 12 N_c + ceil(bbox_c / 8) + 128, E_c = passes over the pixels actually made'},
         'status_counts': {str(k): int(v) for k, v in zip(*np.unique(recs['status'], return_counts=True))},
+        # candidates whose region is separable or all but (psi below 1e-4 of the empty model's N ln 2: "no energy"): status optimal, but inf psi = 0 is not attained and the value is the stopping
+        # rule's -- what cvxopt would report there is unpinned; they never win a set cover (beta >= 100)
+        'near_separable_candidates': int((recs['energy'] < 1e-4 * recs['n_pixels'] * np.log(2)).sum()),
     }
     if rank == 0 and world == 1 and not args.no_extras:
         out['extras'] = extras(args, scene, imgs[0], n_images, scenes)

@@ -2074,7 +2074,7 @@ __global__ void sdsm_k_gate(const int32_t *cls_count, const int32_t *ticket, int
     }
 }
 #ifndef SDSM_GATE_CAP_US
-#define SDSM_GATE_CAP_US 400
+#define SDSM_GATE_CAP_US 150       // (400 until the end of round 4: launches whose group members outnumber the compute units keep drawing tickets one by one and held the gate to its cap)
 #endif
 #ifndef SDSM_GATE_STALL_US
 #define SDSM_GATE_STALL_US 20
