@@ -241,9 +241,14 @@ def _clean_cfg(dsm_cfg):
     cfg = {k: v for k, v in dsm_cfg.items() if k not in _CPU_ONLY_KEYS}
     if callable(cfg.get('init')):
         raise NotImplementedError('dsm/init as a callable is not supported by the GPU solver')
-    for key in ('sparsity_tol', 'hessian_sparsity_tol'):
-        if cfg.pop(key, 0) != 0:
-            raise NotImplementedError(f'dsm/{key} != 0 changes the reference\'s results (dsm.py:346,362,377) and is not implemented by the GPU solver')
+    # dsm/hessian_sparsity_tol (dsm.py:377-383) only drops small entries of the Hessian that the reference hands to its solver: psi and its gradient -- hence the optimum -- do not
+    # change, and the solver here uses an approximate Hessian of its own: accepted and not needed.  dsm/sparsity_tol also zeroes small residuals in the
+    # GRADIENT (dsm.py:346) and curvature weights (dsm.py:362): it moves the point the reference's solver stops at, in a way only cvxopt's iterates define -- refused.
+    hst = cfg.pop('hessian_sparsity_tol', 0)
+    if not (hst >= 0):
+        raise AssertionError('hessian_sparsity_tol must be positive')                  # dsm.py:285
+    if cfg.pop('sparsity_tol', 0) != 0:
+        raise NotImplementedError('dsm/sparsity_tol != 0 changes the reference\'s results (dsm.py:346,362) and is not implemented by the GPU solver')
     return cfg
 
 

@@ -1380,6 +1380,10 @@ def test_launch_refuses_a_workspace_uploaded_before_a_layout_change(gpu, tmp_pat
     assert logs == [f'{i}.txt' for i in range(5)] and 'Newton iterations' in open(tmp_path / 'gen1' / '0.txt').read()
     with pytest.raises(NotImplementedError):
         objects.compute_objects(objs, yi, scene['atoms'], dict(scene['dsm_cfg'], sparsity_tol=1e-3), None, out='muted')
+    # dsm/hessian_sparsity_tol only thins the Hessian the reference hands to cvxopt (dsm.py:377-383): same psi, same gradient, same optimum -- accepted, same results
+    e0 = [o.energy for o in objs]
+    objects.compute_objects(objs, yi, scene['atoms'], dict(scene['dsm_cfg'], hessian_sparsity_tol=1e-3), None, out='muted')
+    assert [o.energy for o in objs] == e0
     # the device-image cache follows the content, not the address
     d0 = objects.device_image(yi, scene['atoms'], 8)
     assert objects.device_image(yi, scene['atoms'], 8) is d0
