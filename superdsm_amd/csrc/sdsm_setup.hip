@@ -18,10 +18,14 @@ namespace {
 // branch): a select between a generic LDS and a generic global pointer compiles to flat loads, which wait for every global store the
 // wavefront has in flight (vmcnt(0)) -- the entries the loop has just written: 1.2 us per grid point in the rows of G~.
 typedef const float __attribute__((address_space(3))) *lds_cfloat_p;
+// (which of the two is a TEMPLATE argument of the loops over the grid points, not a branch inside them: where the two paths of a branch
+// meet the compiler waits for vmcnt(0) -- all global stores of the wavefront included -- whichever path was taken: the loop that writes
+// the entries then waited for its own stores once per grid point, 2-3 us each: 150-260 of the 250-390 us of sdsm_k_setup_rows)
+template <bool PSF_LDS>
 __device__ __forceinline__ float psf_at(const float *psf_lds, const float *psf, int pidx)
 {
-    if (psf_lds) return ((lds_cfloat_p)psf_lds)[pidx];
-    return ((g_cfloat_p)psf)[pidx];
+    if constexpr (PSF_LDS) return ((lds_cfloat_p)psf_lds)[pidx];
+    else return ((g_cfloat_p)psf)[pidx];
 }
 
 struct WeightCtx {
@@ -34,6 +38,7 @@ struct WeightCtx {
     float wmax;             // largest of them
 };
 
+template <bool PSF_LDS>
 __device__ __forceinline__ float wval(WeightCtx &c, int j)
 {
     // (no branch: the eight calls of a group then have their reads of the key and of the PSF table in flight together; a point outside the
@@ -43,7 +48,7 @@ __device__ __forceinline__ float wval(WeightCtx &c, int j)
     const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
     const bool in = adr <= c.R && adc <= c.R;
     const int pidx = in ? (c.R + dr) * c.k + (c.R + dc) : c.R * c.k + c.R;
-    const float t = psf_at(c.psf_lds, c.psf, pidx);
+    const float t = psf_at<PSF_LDS>(c.psf_lds, c.psf, pidx);
     const float v = in ? t : 0.f;
     c.wmax = v > c.wmax ? v : c.wmax;
     c.nnz += in ? 1 : 0;
@@ -53,38 +58,40 @@ __device__ __forceinline__ float wval(WeightCtx &c, int j)
 // numpy's pairwise float32 sum of one block of <= 128 elements (loops_utils.h.src).  Only the grid points j in
 // [c.jlo, c.jhi) can be non-zero; the others are skipped, which changes nothing: an element is added to accumulator
 // (j - lo) % 8 in the order of j as numpy does, and adding +0.0f is exact.
+template <bool PSF_LDS>
 __device__ float pw_block(WeightCtx &c, int lo, int n)
 {
     const int a = lo > c.jlo ? lo : c.jlo, b = lo + n < c.jhi ? lo + n : c.jhi;
     if (a >= b) return 0.f;
     if (n < 8) {
         float res = 0.f;
-        for (int j = a; j < b; j++) res += wval(c, j);
+        for (int j = a; j < b; j++) res += wval<PSF_LDS>(c, j);
         return res;
     }
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f, r5 = 0.f, r6 = 0.f, r7 = 0.f;
     const int nfull = n - (n % 8);
     const int bend = lo + nfull < b ? lo + nfull : b;
     for (int base = lo + ((a - lo) & ~7); base < bend; base += 8) {
-        r0 += wval(c, base); r1 += wval(c, base + 1); r2 += wval(c, base + 2); r3 += wval(c, base + 3);
-        r4 += wval(c, base + 4); r5 += wval(c, base + 5); r6 += wval(c, base + 6); r7 += wval(c, base + 7);
+        r0 += wval<PSF_LDS>(c, base); r1 += wval<PSF_LDS>(c, base + 1); r2 += wval<PSF_LDS>(c, base + 2); r3 += wval<PSF_LDS>(c, base + 3);
+        r4 += wval<PSF_LDS>(c, base + 4); r5 += wval<PSF_LDS>(c, base + 5); r6 += wval<PSF_LDS>(c, base + 6); r7 += wval<PSF_LDS>(c, base + 7);
     }
     float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (int j = lo + nfull > a ? lo + nfull : a; j < b; j++) res += wval(c, j);
+    for (int j = lo + nfull > a ? lo + nfull : a; j < b; j++) res += wval<PSF_LDS>(c, j);
     return res;
 }
 
 // full pairwise recursion (n > 128 splits at n/2 rounded down to a multiple of 8), iteratively
+template <bool PSF_LDS>
 __device__ float pw_sum(WeightCtx &c, int M)
 {
-    if (M <= 128) return pw_block(c, 0, M);
+    if (M <= 128) return pw_block<PSF_LDS>(c, 0, M);
     int s_lo[6], s_n[6], s_stage[6];                     // M <= SDSM_MAX_GRID = 2048: at most 5 levels above the 128-element blocks
     float s_left[6];
     int sp = 0;
     s_lo[0] = 0; s_n[0] = M; s_stage[0] = 0; s_left[0] = 0.f;
     float ret = 0.f;
     while (sp >= 0) {
-        if (s_n[sp] <= 128) { ret = pw_block(c, s_lo[sp], s_n[sp]); sp--; continue; }
+        if (s_n[sp] <= 128) { ret = pw_block<PSF_LDS>(c, s_lo[sp], s_n[sp]); sp--; continue; }
         int n2 = s_n[sp] / 2; n2 -= n2 % 8;
         if (s_stage[sp] == 0) {
             s_stage[sp] = 1;
@@ -95,6 +102,45 @@ __device__ float pw_sum(WeightCtx &c, int M)
         } else { ret = s_left[sp] + ret; sp--; }
     }
     return ret;
+}
+
+// The grid points that can lie inside the PSF windows of a run's pixels, in ascending order of j: those of the rows within R (j in
+// [jlo, jhi), growstart) whose column is within [clo, chi] = [the run's first column - R, its last + R].  The keys are sorted by
+// (row, column): a point left of the range is skipped to the range's start in its row, one right of it to the start in the next row,
+// by binary search.  A region 140 columns wide has ~18 grid points per grid row, 3-4 of them in the range: the loops over the points
+// that writes the entries of a run makes a fifth of the iterations it made over all of [jlo, jhi) (its body is ~150 instructions; the cheap
+// loops -- entry count, row sums -- are faster over all points: a skip is two dependent chains of LDS reads, divergent across the lanes).
+struct GridCursor {
+    const uint32_t *keys;
+    int j, jhi;
+    uint32_t clo, chi;
+    __device__ __forceinline__ int lower_bound(uint32_t key, int lo) const
+    {
+        int hi = jhi;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+        return lo;
+    }
+    __device__ __forceinline__ void settle()             // forward to the next point inside the column range (or to jhi)
+    {
+        while (j < jhi) {
+            const uint32_t key = keys[j], col = key & 0xffffu, row = key >> 16;
+            if (col < clo) j = lower_bound((row << 16) | clo, j + 1);
+            else if (col > chi) j = lower_bound(((row + 1) << 16) | clo, j + 1);
+            else break;
+        }
+    }
+    __device__ __forceinline__ void next() { j++; settle(); }
+};
+__device__ __forceinline__ GridCursor grid_cursor(const uint32_t *keys, int jlo, int jhi, const int (&cck)[SDSM_RUN], int R)
+{
+    int cmin = 1 << 20, cmax = -1;
+#pragma unroll
+    for (int k = 0; k < SDSM_RUN; k++) if (cck[k] >= 0) { cmin = cck[k] < cmin ? cck[k] : cmin; cmax = cck[k] > cmax ? cck[k] : cmax; }
+    GridCursor g;
+    g.keys = keys; g.j = jlo; g.jhi = cmax >= 0 ? jhi : jlo;   // (a run without pixels: nothing)
+    g.clo = (uint32_t)(cmin - R > 0 ? cmin - R : 0); g.chi = (uint32_t)(cmax + R);
+    g.settle();
+    return g;
 }
 
 __device__ __forceinline__ int cheb(int r0, int c0, int r1, int c1)
@@ -160,16 +206,27 @@ __device__ __forceinline__ void plain_runs(const BatchParams &P, const CandDesc 
     }
 }
 
+#ifdef SDSM_PROFILE
+#define ROWS_PROF_PARAM , long long (&rows_t)[5]
+#define ROWS_PROF_ARG , rows_t
+#define ROWS_T(k) do { long long _n = PROF_NOW(); rows_t[k] += _n - rows_t[4]; rows_t[4] = _n; } while (0)
+#else
+#define ROWS_PROF_PARAM
+#define ROWS_PROF_ARG
+#define ROWS_T(k) do { } while (0)
+#endif
 // G~ of the raster runs [rr0, rr1) of a candidate: per pixel the PSF gather, numpy's pairwise float32 row sum and the float32
 // division (dsm.py:192-193), exactly as the reference builds the pixel's row; per run ONE pass over the grid points of the rows
 // within R that writes an entry for every point inside the window of at least one of its pixels (weight 0 for the others).
 // Runs are taken in RASTER order: the 64 lanes of a wavefront then sit next to each other in the image, see (almost) the same
 // grid points and take the same branches in the loops over them.  efirst (LDS, M ints, initialised to j): first coupled column.
+template <bool PSF_LDS>
 __device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDesc &cd, int NR, uint32_t B, int M, int R, int hc, const uint32_t *gridkeys,
                                              const uint16_t *growstart, const float *psf_lds, int *efirst, int rr0, int rr1, int step,
-                                             bool &bad, int &hzmax)
+                                             bool &bad, int &hzmax ROWS_PROF_PARAM)
 {
     for (int rr = rr0; rr < rr1; rr += step) {
+        ROWS_T(3);
         const int si = (int)(((unsigned long long)rr * B) % (unsigned long long)NR);
         const int pos = (int)P.inv[cd.crop_off + si];
         const int nnz = (int)P.dist[cd.crop_off + si];
@@ -192,6 +249,7 @@ __device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDes
 #pragma unroll
         for (int k = 0; k < SDSM_RUN; k++) yo[k] = yk[k];
         P.crop_rc[cd.run_off + pos] = rc0;
+        ROWS_T(0);
         // pass 1, per pixel: row sum in numpy's order, largest entry, number of entries (nothing is stored)
         const int jlo = growstart[cr - R > 0 ? cr - R : 0], jhi = cr + R + 1 < hc ? growstart[cr + R + 1] : M;
         float sumk[SDSM_RUN], limk[SDSM_RUN];
@@ -203,7 +261,7 @@ __device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDes
                 WeightCtx c;
                 c.cr = cr; c.cc = cck[k]; c.R = R; c.k = P.k; c.psf = P.psf; c.psf_lds = psf_lds; c.keys = gridkeys; c.nnz = 0; c.wmax = 0.f;
                 c.jlo = jlo; c.jhi = jhi;
-                const float sum = pw_sum(c, M);
+                const float sum = pw_sum<PSF_LDS>(c, M);
                 if (c.nnz > P.zcap || !(sum > 0.f)) rowbad = true;                      // dsm.py:194
                 sumk[k] = sum;
                 limk[k] = P.hess_thr * __fdiv_rn(c.wmax, sum);
@@ -217,13 +275,15 @@ __device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDes
         double rsumk[SDSM_RUN];
 #pragma unroll
         for (int k = 0; k < SDSM_RUN; k++) rsumk[k] = 1.0 / (double)sumk[k];
+        ROWS_T(1);
         // pass 2: one entry per grid point inside the window of at least one pixel: the normalised weights of the four pixels and
         // the pixels for which the entry is a LEADING one (>= hess_thr * the pixel's row maximum: the solver's approximate Hessian
         // uses only those; S and the gradient use all).  Leading entries fill the slots from 0 upwards -- in ascending column
         // order, so the solve kernel knows which of a pair is the row --, the others from slot nnz - 1 downwards.
         const int64_t base = cd.ell_off + pos;
         int hz = 0, others = 0, hzk[SDSM_RUN] = {0, 0, 0, 0}, mn[SDSM_RUN] = {0, 0, 0, 0};
-        for (int j = jlo; j < jhi; j++) {
+        for (GridCursor gq = grid_cursor(gridkeys, jlo, jhi, cck, R); gq.j < gq.jhi; gq.next()) {   // (the points within the columns of the run's windows only)
+            const int j = gq.j;
             const uint32_t gk = gridkeys[j];
             const int dr = (int)(gk >> 16) - cr, gc = (int)(gk & 0xffffu);
             if ((dr < 0 ? -dr : dr) > R) continue;
@@ -238,7 +298,7 @@ __device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDes
                 const int dc = gc - cck[k];
                 ink[k] = (dc < 0 ? -dc : dc) <= R;
                 const int pidx = ink[k] ? (R + dr) * P.k + (R + dc) : R * P.k + R;
-                tv[k] = psf_at(psf_lds, P.psf, pidx);
+                tv[k] = psf_at<PSF_LDS>(psf_lds, P.psf, pidx);
                 any = any || ink[k];
             }
 #pragma unroll
@@ -272,6 +332,7 @@ __device__ __forceinline__ void rows_of_runs(const BatchParams &P, const CandDes
         }
         P.run_meta[cd.run_off + pos] = (uint32_t)nnz | ((uint32_t)hz << 12) | (rp.mask << 24);
         hzmax = hz > hzmax ? hz : hzmax;
+        ROWS_T(2);
     }
 }
 
@@ -731,7 +792,11 @@ __device__ __forceinline__ void setup_candidate(const BatchParams &P)
     }
     bool bad = false;
     int hzmax = 0;
-    rows_of_runs(P, cd, NR, B, M, R, hc, gridkeys, growstart, psf_lds, efirst, tid, NR, T::WG, bad, hzmax);
+#ifdef SDSM_PROFILE
+    long long rows_t[5] = {0, 0, 0, 0, PROF_NOW()};
+#endif
+    if (psf_lds) rows_of_runs<true>(P, cd, NR, B, M, R, hc, gridkeys, growstart, psf_lds, efirst, tid, NR, T::WG, bad, hzmax ROWS_PROF_ARG);
+    else rows_of_runs<false>(P, cd, NR, B, M, R, hc, gridkeys, growstart, psf_lds, efirst, tid, NR, T::WG, bad, hzmax ROWS_PROF_ARG);
     if (bad) atomicOr(&sh_err, 1);
     hzmax = -block_min_i32<T::WG / 64>(-hzmax, scr32);
     __syncthreads();
@@ -767,6 +832,9 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
     __shared__ int scr32[SDSM_WAVES];
     __shared__ int sh_last;
     const int tid = threadIdx.x;
+#ifdef SDSM_PROFILE
+    long long rt0 = PROF_NOW(), rt1 = 0, rt2 = 0;
+#endif
     const int entry = P.order[blockIdx.x];
     const int ci = entry & 0xffffff, g = (entry >> 24) & 0xff;
     const CandDesc cd = P.cand[ci];
@@ -792,7 +860,15 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
     const int q0 = g * chunk < NR ? g * chunk : NR, q1 = q0 + chunk < NR ? q0 + chunk : NR;
     bool bad = false;
     int hzmax = 0;
-    rows_of_runs(P, cd, NR, B, M, R, hc, gridkeys, growstart, psf_lds, efirst, q0 + tid, q1, SDSM_WG, bad, hzmax);
+#ifdef SDSM_PROFILE
+    rt1 = PROF_NOW();
+    long long rows_t[5] = {0, 0, 0, 0, rt1};
+#endif
+    if (psf_lds) rows_of_runs<true>(P, cd, NR, B, M, R, hc, gridkeys, growstart, psf_lds, efirst, q0 + tid, q1, SDSM_WG, bad, hzmax ROWS_PROF_ARG);
+    else rows_of_runs<false>(P, cd, NR, B, M, R, hc, gridkeys, growstart, psf_lds, efirst, q0 + tid, q1, SDSM_WG, bad, hzmax ROWS_PROF_ARG);
+#ifdef SDSM_PROFILE
+    rt2 = PROF_NOW();
+#endif
     hzmax = -block_min_i32(-hzmax, scr32);
     __syncthreads();
     for (int j = tid; j < M; j += SDSM_WG) if (efirst[j] < j) atomicMin(&P.env_fst[cd.xi_off + j], efirst[j]);
@@ -808,6 +884,9 @@ __global__ __launch_bounds__(SDSM_WG) void sdsm_k_setup_rows(BatchParams P)
     if (tid == 0) {
         st->env_size = envelope_from_first(P, cd, M, efirst);
         if (__hip_atomic_load(&sync[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) st->status = ST_ERROR;
+#ifdef SDSM_PROFILE
+        if (P.prof2) { P.prof2[(size_t)ci * 8 + 7] = rt1 - rt0; P.prof2[(size_t)ci * 8 + 5] = rt2 - rt1; P.prof2[(size_t)ci * 8 + 6] = PROF_NOW() - rt2; P.prof2[(size_t)ci * 8 + 0] = rows_t[0] + rows_t[3]; P.prof2[(size_t)ci * 8 + 1] = rows_t[1]; P.prof2[(size_t)ci * 8 + 2] = rows_t[2]; }   // (the last member's: prologue, its runs, meeting + envelope)
+#endif
     }
 }
 
