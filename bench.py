@@ -339,7 +339,7 @@ def main():
                      'kernel': 'sdsm_k_solve: the size classes of one launch, which run concurrently on four queues (class 1 <128, 2560, .., 192> holds '
                                f'{int(((recs["n_deform"] + 6 <= 128)).sum())} of the {len(recs)} candidates; the longest chains are the workgroup groups of the 10-17 k-pixel clusters and class 1b); '
                                'kernel_ms = HIP events on the launch stream from the end of sdsm_k_setup to the join of the classes (includes sdsm_k_setup_rows, the rows of G~ of the '
-                               'regions above 4096 pixels); per-class rocprofv3 averages: profiles/r03_kernel_stats.csv',
+                               'regions above 4096 pixels); per-class rocprofv3 averages: profiles/r04_kernel_stats.csv',
                      'kernel_ms': kern_ms, 'setup_kernel_ms': float(np.mean(setup_ms)), 'algorithmic_bytes_per_launch': alg_bytes,
                      'achieved_in_timed_region': alg_bytes / (dt / args.steps) / 1e9,
                      'fp64_vector_tflops': flops / (kern_ms * 1e-3) / 1e12, 'fp64_vector_frac_of_78.6': flops / (kern_ms * 1e-3) / 1e12 / 78.6,
