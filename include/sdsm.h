@@ -247,6 +247,17 @@ int64_t sdsm_unpack_fragments(const sdsm_record *records, const int32_t *mask_in
  * d_out: sdsm_plan_eval_out_count() doubles: [2 i], [2 i + 1] psi by the full and by the value-only evaluator;
  * [2 n + 21 i ..] lower triangle (row-major) of the 6x6 theta block of the Hessian; [23 n + 6 i + xi_offset[i] ..] the
  * gradient in the layout of d_params.  Candidates without a solve (trivial, failed, beyond the limits) get NaN. */
+/* Callable dsm/init (reference: superdsm/objects.py:385-386, `params = init(J.smooth_mat.shape[1])`): the caller's own starting point of
+ * the DSM solve instead of the elliptical model's optimum.  The number of columns of a candidate's G~ -- its grid points -- is a result
+ * of the setup kernel: sdsm_batch_deform_counts runs it alone (arguments as sdsm_batch_launch_multi), SYNCHRONISES the stream and writes
+ * n_deform[i] = M of candidate i to host memory (-1: no solve -- trivial region, failed setup; 0 also for a system beyond the solver's
+ * limit, which gets the elliptical model only).  sdsm_plan_set_start then names the starting points of the following launches: d_x0 =
+ * sdsm_plan_eval_param_count() doubles on the device, candidate i's theta[6] (full-image-normalised) + xi[M] at 6 * i + xi_offset[i]
+ * (the layout of sdsm_batch_eval's d_params); it must stay valid until those launches have completed; NULL = none.  Only for plans with
+ * init_elliptical = 0 (SDSM_ERR_ARGUMENT otherwise); a candidate whose solve falls back (SDSM_CAND_FALLBACK) returns the initialisation. */
+int sdsm_batch_deform_counts(const sdsm_plan *plan, const double *const *d_y, const int32_t *const *d_atoms, const uint8_t *const *d_valid,
+                             void *d_workspace, size_t workspace_bytes, int32_t *n_deform, void *stream);
+int sdsm_plan_set_start(const sdsm_plan *plan, const double *d_x0);
 int64_t sdsm_plan_eval_param_count(const sdsm_plan *plan);
 int64_t sdsm_plan_eval_out_count(const sdsm_plan *plan);
 int sdsm_batch_eval(const sdsm_plan *plan, void *d_workspace, size_t workspace_bytes, const double *d_params, double *d_out, void *stream);

@@ -76,6 +76,8 @@ SYMBOLS = {
     'sdsm_plan_eval_param_count': (_i64, [_vp]),
     'sdsm_plan_eval_out_count': (_i64, [_vp]),
     'sdsm_batch_eval': (_i32, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    'sdsm_batch_deform_counts': (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'sdsm_plan_set_start': (_i32, [_vp, _vp]),
     'sdsm_enable_kernel_timing': (_i32, [_i32]),
     'sdsm_last_solve_kernel_ms': (_f64, []),
     'sdsm_last_setup_kernel_ms': (_f64, []),
@@ -122,4 +124,4 @@ def make_config(dsm_cfg):
     return DsmConfig(scale=float(d.get('scale', 1000)), epsilon=float(d.get('epsilon', 1.0)), alpha=float(d.get('alpha', 0.5)),
                      smooth_amount=float(sa), gaussian_shape_multiplier=float(d.get('gaussian_shape_multiplier', 2)),
                      background_margin=float(d.get('background_margin', 20)), smooth_subsample=int(d.get('smooth_subsample', 20)),
-                     init_elliptical=int(d.get('init', 'elliptical') == 'elliptical'), max_iters=int(d.get('max_iters', 100)), flags=1 if d.get('no_trivial_rule') else 0)
+                     init_elliptical=int(not callable(d.get('init', 'elliptical')) and d.get('init', 'elliptical') == 'elliptical'), max_iters=int(d.get('max_iters', 100)), flags=1 if d.get('no_trivial_rule') else 0)

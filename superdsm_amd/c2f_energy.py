@@ -37,6 +37,8 @@ def normalized_energies(y_crop, mask_crop, atoms_map, footprints, dsm_cfg):
     img = engine.DeviceImage(np.ascontiguousarray(y_crop, np.float64), None if mask_crop is None else np.ascontiguousarray(mask_crop, bool),
                              np.ascontiguousarray(atoms_map, np.int32), margin)
     batch = engine.Batch(img, footprints, cfg, latency_mode=True)
+    from .objects import _starting_points
+    _starting_points(batch, cfg)                              # callable dsm/init (objects.py:385-386): init(0) here, G~ is the null matrix
     batch.launch()
     recs = batch.records()
     out = []

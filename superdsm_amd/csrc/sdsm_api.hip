@@ -144,6 +144,7 @@ struct sdsm_plan {
     // The launch lists and CandDesc.wide_* live in the workspace (sdsm_batch_upload): a layout change after the upload
     // (sdsm_plan_set_latency_mode) would leave stale tables on the device, so launches check the generation they were uploaded at.
     uint64_t layout_gen = 0;
+    mutable const double *x0 = nullptr;   // sdsm_plan_set_start: device pointer to the starting points of the DSM solves, or null
     mutable uint64_t uploaded_gen = 0;
     mutable const void *uploaded_ws = nullptr;
     // side streams / fork-join events of the solve classes, owned by the plan (created at its first launch)
@@ -586,6 +587,7 @@ static BatchParams make_params(const sdsm_plan *p, void *d_ws)
     P.wide_ticket = (int32_t *)(b + p->off_ticket); P.wide_timeout = g_wide_timeout;
     P.cls_count = (int32_t *)(b + p->off_ticket) + 16;
     P.prof = g_prof; P.prof2 = g_prof ? g_prof + (size_t)16 * p->n : nullptr;
+    P.x0 = p->x0;
     return P;
 }
 
@@ -647,6 +649,44 @@ extern "C" int sdsm_batch_launch_multi(const sdsm_plan *p, const double *const *
         if ((e = sdsm_launch_solve(P, d_records, d_masks, d_xi, s, s1, s2, s3, p->sides ? p->sides->side[3] : nullptr, fj, p->n_order_c, p->n_order_d, p->n_order_w, p->n_order_r)) != hipSuccess) return hipfail(e, "launch solve");
     }
     if (g_timing) { if ((e = hipEventRecord(g_ev[2], s)) != hipSuccess) return hipfail(e, "hipEventRecord"); g_ev_valid = 1; }
+    return SDSM_OK;
+}
+
+// ---- callable dsm/init (objects.py:385-386: params = init(number of columns of G~)) -----------------------------------------
+// The number of columns of a candidate's G~ (its grid points, dsm.py:159-181) is known once the setup kernel has run: this runs
+// it alone and returns the counts to the HOST (it synchronises the stream): n_deform[i] = M of candidate i, -1 for a candidate
+// without a solve (trivial, failed setup).  The caller then builds the starting points and hands them over with sdsm_plan_set_start.
+extern "C" int sdsm_batch_deform_counts(const sdsm_plan *p, const double *const *d_y, const int32_t *const *d_atoms, const uint8_t *const *d_valid,
+                                        void *d_ws, size_t ws_bytes, int32_t *n_deform, void *stream)
+{
+    if (!p || !d_y || !d_atoms || !d_valid || !d_ws || !n_deform) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_deform_counts: null argument");
+    for (size_t i = 0; i < p->images.size(); i++) if (!d_y[i] || !d_atoms[i] || !d_valid[i]) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_deform_counts: null image pointer");
+    if (p->uploaded_gen != p->layout_gen || p->uploaded_ws != d_ws) return fail(SDSM_ERR_ARGUMENT, "sdsm_batch_deform_counts: the plan's tables in this workspace are missing or stale (sdsm_batch_upload)");
+    if (ws_bytes < p->total) return fail(SDSM_ERR_WORKSPACE, "sdsm_batch_deform_counts: workspace too small");
+    if (p->n == 0) return SDSM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    BatchParams P = make_params(p, d_ws);
+    for (size_t i = 0; i < p->images.size(); i++) { P.img[i].y = d_y[i]; P.img[i].atoms = d_atoms[i]; P.img[i].valid = d_valid[i]; }
+    hipError_t e;
+    const int32_t *lists = P.order + p->n + p->n_order_c + p->n_order_d;
+    if ((e = sdsm_launch_setup(P, s, lists, p->n_order_w, p->setup_class, lists + p->n_order_w + p->n_order_r, p->n_setup_small, lists + p->n_order_w + p->n_order_r + p->n_setup_small, p->n_setup_big)) != hipSuccess)
+        return hipfail(e, "launch setup");
+    std::vector<CandState> st(p->n);
+    if ((e = hipMemcpyAsync(st.data(), (const uint8_t *)d_ws + p->off_state, sizeof(CandState) * p->n, hipMemcpyDeviceToHost, s)) != hipSuccess) return hipfail(e, "hipMemcpyAsync");
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return hipfail(e, "hipStreamSynchronize");
+    for (int i = 0; i < p->n; i++) n_deform[i] = st[i].status == ST_OK ? (6 + st[i].M > SDSM_MAX_N_GLOBAL ? 0 : st[i].M) : -1;   // (beyond the solver's limit: elliptical model only)
+    return SDSM_OK;
+}
+
+// Starting points of the DSM solves of the following launches of this plan: d_x0 holds sdsm_plan_eval_param_count() doubles in the layout of
+// sdsm_batch_eval's d_params (candidate i: theta[6] in full-image-normalised coordinates, then xi[M], at 6 i + xi_offset[i]) and must stay
+// valid until those launches have completed; null = none.  Only plans created with init_elliptical = 0 read it; a fallback
+// (SDSM_CAND_FALLBACK) then returns this initialisation, as the reference does (objects.py:409-410).
+extern "C" int sdsm_plan_set_start(const sdsm_plan *p, const double *d_x0)
+{
+    if (!p) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_set_start: null plan");
+    if (d_x0 && p->cfg.init_elliptical) return fail(SDSM_ERR_ARGUMENT, "sdsm_plan_set_start: the plan solves the elliptical model first (init_elliptical = 1)");
+    p->x0 = d_x0;
     return SDSM_OK;
 }
 

@@ -179,6 +179,7 @@ struct BatchParams {
     double *hglob;                     // Hessian pool of the global-memory class (envelope too large for LDS), CandDesc.hglob_off
     long long *prof;                   // diagnostic build only (-DSDSM_PROFILE): 16 cycle counters per candidate (solve kernel)
     long long *prof2;                  // diagnostic build only: 8 cycle counters per candidate (setup kernel), behind the 16 n solve counters
+    const double *x0;                  // null, or the caller's starting points of the DSM solves (callable dsm/init, objects.py:385-386): candidate i's theta[6] (full-image-normalised) + xi[M] at 6 i + xi_off(i), as sdsm_batch_eval takes them; only read if init_elliptical == 0
 };
 
 // Solve class of a candidate once its setup is complete: the FIRST class whose limits (6 + M <= NMAX, Hessian envelope <= EMAX

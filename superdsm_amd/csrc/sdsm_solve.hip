@@ -60,6 +60,9 @@ namespace {
 #ifndef SDSM_K1_THREADS
 #define SDSM_K1_THREADS 192
 #endif
+#ifndef SDSM_K1_WPE
+#define SDSM_K1_WPE 3             // wavefronts per SIMD the throughput-mode class 1 is compiled for (4 = 128 registers: spills, measured slower)
+#endif
 #ifndef SDSM_K1B_THREADS
 #define SDSM_K1B_THREADS 256       // (384 threads at three wavefronts per SIMD: synthetic 4096^2 93 vs 84 ms)
 #define SDSM_K1B_WPE 2
@@ -1701,7 +1704,15 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
             if (P.init_elliptical && !have) { status_final = SDSM_CAND_ERROR; break; }   // CvxprogError (objects.py:351-353)
             M = Mfull;
             __syncthreads();
-            for (int i = tid; i < NMAX; i += L::WGS) x[i] = i < 6 ? keep[i] : 0;
+            const double *x0 = (!P.init_elliptical && P.x0) ? P.x0 + (size_t)6 * ci + cd.xi_off : nullptr;   // callable dsm/init: the caller's starting point
+            if (x0) {
+                const Frame fr = make_frame(c, P.img[cd.image].H, P.img[cd.image].W);
+                double thg[6], thl[6];
+                for (int i = 0; i < 6; i++) thg[i] = x0[i];
+                reparam(thg, fr.P0, fr.P1, fr.O0, fr.O1, thl);                     // (every thread: the same values)
+                for (int i = 0; i < 6; i++) keep[i] = uni(thl[i]);
+            }
+            for (int i = tid; i < NMAX; i += L::WGS) x[i] = i < 6 ? keep[i] : (x0 && i < 6 + M ? x0[i] : 0);
             if (M > 0) {                                                         // envelope of the Hessian (setup kernel)
                 int *rbp = RBP, *fstp = FSTP, *rendp = RENDP;
                 const int exi = efull - 6 * M - 21;
@@ -1740,7 +1751,10 @@ __device__ __forceinline__ void solve_candidate(const BatchParams &P, int ci, in
                 // comes from the value-only evaluator, psi from the full one: the same sums in a different reduction order, so
                 // "worse" allows for rounding (same rule in the oracle)
                 __syncthreads();
-                for (int i = tid; i < NMAX; i += L::WGS) xt[i] = i < 6 ? keep[i] : 0;
+                {
+                    const double *x0 = (!P.init_elliptical && P.x0) ? P.x0 + (size_t)6 * ci + cd.xi_off : nullptr;   // the fallback is the initialisation (objects.py:409-410)
+                    for (int i = tid; i < NMAX; i += L::WGS) xt[i] = i < 6 ? keep[i] : (x0 && i < 6 + Mfull ? x0[i] : 0);
+                }
                 __syncthreads();
                 const double vi = eval_value<L>(c, L::XT, Mfull);
                 ev_value++;
@@ -2195,7 +2209,7 @@ extern "C" hipError_t sdsm_launch_solve(const BatchParams &P, sdsm_record *recor
     static const int resident_1 = [] { const char *e = getenv("SDSM_RESIDENT_1"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SDSM_RESIDENT_1; }();   // (diagnostic knob)
     const int g_1 = P.n < resident_1 ? P.n : resident_1;
     if (first == hipSuccess) {
-        if (!P.latency) keep(launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream));
+        if (!P.latency) keep(launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, SDSM_K1_WPE, false, SDSM_K1_THREADS, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream));
         else keep(launch_class<SDSM_K1_NMAX, SDSM_K1_EMAX, 3, false, 256, false, SDSM_CLS_1>(P, g_1, 4, 1, records, masks, xi_out, stream));
     }
     // join (also after an error: whatever was forked is recorded and waited for)

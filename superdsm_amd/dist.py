@@ -91,6 +91,8 @@ def _gpu_solve_local(image, footprints, cfg, mask_info, cache=None):
         from .objects import LATENCY_MODE_BELOW
         batch = engine.Batch(image, footprints, cfg, mode=1 if len(footprints) < LATENCY_MODE_BELOW else 0)
         assert np.array_equal(batch.mask_info[:len(footprints)], mask_info), 'plan of the shard disagrees with the replicated layout'
+        from .objects import _starting_points
+        batch.start = _starting_points(batch, cfg)           # callable dsm/init: starting points of this shard's candidates (None otherwise)
         if cache is not None:
             cache['batch'] = batch
     batch.launch()
@@ -102,6 +104,8 @@ def _gpu_solve_local(image, footprints, cfg, mask_info, cache=None):
         again = torch.nonzero(rec32[:n, 16] == _capi.CAND_GIVEN_UP).flatten().cpu().numpy()       # (status: int32 #16 of the 128-byte record)
         if again.size:
             sub = engine.Batch(image, [footprints[i] for i in again], cfg, mode=2)
+            if batch.start is not None:
+                sub.set_start([batch.start[i] for i in again])
             sub.launch()
             sub32 = sub.records_dev.view(torch.int32).reshape(-1, 32)
             for j, i in enumerate(again):

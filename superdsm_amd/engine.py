@@ -213,6 +213,31 @@ class Batch:
             _capi.check(L.sdsm_batch_launch_multi(self.plan, self._ptrs[0], self._ptrs[1], self._ptrs[2], _ptr(self.ws), self.ws_bytes,
                                                   _ptr(self.records_dev), _ptr(self.masks_dev), _ptr(self.xi_dev), _stream()), 'sdsm_batch_launch_multi')
 
+    def deform_counts(self):
+        """Number of columns of every candidate's G~ (its grid points; -1: no solve), from a run of the setup kernel alone
+        (sdsm_batch_deform_counts; synchronises): what a callable ``dsm/init`` is called with (objects.py:385-386)."""
+        L = _capi.lib()
+        m = np.full(max(self.n, 1), -1, np.int32)
+        with torch.cuda.device(self.image.device):
+            _capi.check(L.sdsm_batch_deform_counts(self.plan, self._ptrs[0], self._ptrs[1], self._ptrs[2], _ptr(self.ws), self.ws_bytes,
+                                                   m.ctypes.data_as(C.c_void_p), _stream()), 'sdsm_batch_deform_counts')
+        return m[:self.n]
+
+    def set_start(self, params):
+        """Starting points of the DSM solves of the following launches (sdsm_plan_set_start): ``params[i]`` = theta (6,
+        full-image-normalised) + xi (M) of candidate i, or None for a candidate without a solve.  Only for plans with
+        ``init`` other than ``'elliptical'``."""
+        L = _capi.lib()
+        xo = self.xi_offsets()
+        buf = np.zeros(L.sdsm_plan_eval_param_count(self.plan))
+        for i, p in enumerate(params):
+            if p is None:
+                continue
+            p = np.asarray(p, np.float64).ravel()
+            buf[6 * i + xo[i]:6 * i + xo[i] + p.size] = p
+        self.x0_dev = torch.from_numpy(buf).to(self.image.device)       # (kept alive by the batch)
+        _capi.check(L.sdsm_plan_set_start(self.plan, _ptr(self.x0_dev)), 'sdsm_plan_set_start')
+
     def download(self):
         """Records and bit-packed masks to pinned host staging buffers: two asynchronous copies on the current stream, one
         synchronisation.  Returns (records structured array, masks uint8 array) -- VIEWS of the staging buffers, which are shared

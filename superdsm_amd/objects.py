@@ -184,6 +184,7 @@ def _solve(images, footprints, image_of, cfg, shard, while_waiting=None):
         return shard.solve(images[0], footprints, cfg)
     batch = engine.Batch(images if len(images) > 1 else images[0], footprints, cfg, image_of=image_of,
                          mode=1 if len(footprints) < LATENCY_MODE_BELOW else 0)   # a batch that cannot fill the GPU: shortest wall clock
+    start = _starting_points(batch, cfg)
     batch.launch()
     if while_waiting is not None:                          # host work of the caller while the kernels run (the launch is asynchronous)
         while_waiting()
@@ -194,6 +195,8 @@ def _solve(images, footprints, image_of, cfg, shard, while_waiting=None):
     if again.size:
         sub = engine.Batch(images if len(images) > 1 else images[0], [footprints[i] for i in again], cfg,
                            image_of=None if image_of is None else np.asarray(image_of)[again], mode=2)
+        if start is not None:
+            sub.set_start([start[i] for i in again])
         sub.launch()
         rec2, masks2 = sub.download()
         frag2 = sub.fragments(rec2, masks=masks2, lazy=True)
@@ -201,6 +204,26 @@ def _solve(images, footprints, image_of, cfg, shard, while_waiting=None):
             records[i] = rec2[j]
             fragments[i] = frag2[j]
     return records, fragments
+
+
+def _starting_points(batch, cfg):
+    """Callable ``dsm/init`` (objects.py:385-386): ``params = init(number of columns of G~)`` per candidate -- the count is a result of
+    the setup kernel, which runs once on its own for it -- handed to the batch as the starting points of its DSM solves.  Returns the
+    list of vectors (None for candidates without a solve), or None if ``init`` is not callable."""
+    init = cfg.get('init')
+    if not callable(init):
+        return None
+    start = []
+    for i, m in enumerate(batch.deform_counts().tolist()):
+        if m < 0:
+            start.append(None)
+            continue
+        p = np.asarray(init(m), np.float64).ravel()
+        if p.size != 6 + m or not np.all(np.isfinite(p)):
+            raise ValueError(f'dsm/init({m}) must return {6 + m} finite parameters (candidate {i}: got {p.size})')
+        start.append(p)
+    batch.set_start(start)
+    return start
 
 
 def _assign(objects, records, fragments, dt, cidx0=0):
@@ -239,8 +262,6 @@ def _assign(objects, records, fragments, dt, cidx0=0):
 
 def _clean_cfg(dsm_cfg):
     cfg = {k: v for k, v in dsm_cfg.items() if k not in _CPU_ONLY_KEYS}
-    if callable(cfg.get('init')):
-        raise NotImplementedError('dsm/init as a callable is not supported by the GPU solver')
     # dsm/hessian_sparsity_tol (dsm.py:377-383) only drops small entries of the Hessian that the reference hands to its solver: psi and its gradient -- hence the optimum -- do not
     # change, and the solver here uses an approximate Hessian of its own: accepted and not needed.  dsm/sparsity_tol also zeroes small residuals in the
     # GRADIENT (dsm.py:346) and curvature weights (dsm.py:362): it moves the point the reference's solver stops at, in a way only cvxopt's iterates define -- refused.

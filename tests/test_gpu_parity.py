@@ -1357,6 +1357,67 @@ def test_groups_of_both_lds_layouts_give_the_bytes_of_single_workgroups(gpu):
         k0 += len(sc['footprints'])
 
 
+def test_callable_dsm_init_starts_the_deformable_solve_where_the_caller_says(gpu):
+    """dsm/init as a callable (reference: objects.py:385-386, ``params = init(J.smooth_mat.shape[1])``): it is called with the number of columns of
+    the candidate's G~ -- known after the setup kernel -- and its return value is where the DSM solve starts (no elliptical model first).
+    init(m) = zeros is the reference's ``init=None`` path: the same bytes; another start: the oracle's solver from the same point reaches
+    the same energy, and the reported energy is the reference's energy function at the returned parameters."""
+    from oracle import oracle
+    from superdsm_amd import _capi, engine, image, objects, testing
+    scene = testing.make_scene('synthetic256', max_size=2)
+    fps, cfg = scene['footprints'][:40], scene['dsm_cfg']
+    img = engine.DeviceImage(scene['y'], None, scene['atoms'], cfg['background_margin'])
+    b0 = engine.Batch(img, fps, dict(cfg, init=None))
+    b0.launch()
+    r0 = b0.records()
+    called = []
+    def zeros(m):
+        called.append(m)
+        return np.zeros(6 + m)
+    b1 = engine.Batch(img, fps, dict(cfg, init=zeros))
+    start = objects._starting_points(b1, dict(cfg, init=zeros))
+    b1.launch()
+    r1 = b1.records()
+    assert r0.tobytes() == r1.tobytes()
+    solved = r0['status'] != _capi.CAND_TRIVIAL
+    assert solved.sum() >= 30 and called == r0['n_deform'][solved].tolist() and [s is not None for s in start] == solved.tolist()
+    with pytest.raises(_capi.SdsmError, match='elliptical'):                # a plan that solves the elliptical model first has no use for starting points
+        engine.Batch(img, fps, cfg).set_start(start)
+    # a start of its own: a circle around the image centre and small alternating deformations
+    def circle(m):
+        xi = 0.01 * (-1.0) ** np.arange(m)
+        return np.concatenate([[-100.0, -100.0, 0.0, 50.0, 50.0, -49.0], xi])
+    yi = image.Image.create_from_array(scene['y'], normalize=False)
+    objs = [objects.Object() for _ in fps]
+    for o, fp in zip(objs, fps):
+        o.footprint = set(fp)
+    objects.compute_objects(objs, yi, scene['atoms'], dict(cfg, init=circle), None, out='muted')
+    with pytest.raises(ValueError, match='finite parameters'):
+        objects.compute_objects(objs[:3], yi, scene['atoms'], dict(cfg, init=lambda m: np.zeros(5 + m)), None, out='muted')
+    b2 = engine.Batch(img, fps, dict(cfg, init=circle), want_xi=True)
+    objects._starting_points(b2, dict(cfg, init=circle))
+    b2.launch()
+    r2, xi, xo = b2.records(), b2.xi_dev.cpu().numpy(), b2.xi_offsets()
+    checked = 0
+    for k in np.flatnonzero(solved)[:12]:
+        mask = oracle.region_mask(scene['y'], None, scene['atoms'], fps[k], cfg['background_margin'])
+        J = oracle.Energy(scene['y'], mask, cfg['epsilon'], cfg['alpha'], cfg['smooth_amount'], cfg['gaussian_shape_multiplier'], cfg['smooth_subsample'])
+        assert J.M == r2['n_deform'][k]
+        p = np.concatenate([r2['theta'][k], xi[xo[k]:xo[k] + J.M]])
+        assert abs(J(p) - r2['energy'][k]) <= 1e-9 * max(1.0, abs(r2['energy'][k]))
+        assert objs[k].energy == r2['energy'][k]                            # compute_objects went the same way
+        x, info = J.newton(circle(J.M), cfg['scale'] / J.N)
+        if info['status'] == 0 and r2['status'][k] == _capi.CAND_OPTIMAL:
+            tol = 1e-6 * J.N / 1000 + 1e-5 * abs(info['value'])
+            assert abs(r2['energy'][k] - info['value']) <= tol, (k, r2['energy'][k], info['value'])
+            checked += 1
+        else:                                                               # fallback: the initialisation itself (objects.py:409-410)
+            assert r2['status'][k] in (_capi.CAND_FALLBACK, _capi.CAND_OPTIMAL)
+            if r2['status'][k] == _capi.CAND_FALLBACK:
+                np.testing.assert_allclose(p, circle(J.M), rtol=1e-12, atol=1e-12)
+    assert checked >= 6, checked
+
+
 def test_launch_refuses_a_workspace_uploaded_before_a_layout_change(gpu, tmp_path):
     """sdsm_plan_set_latency_mode changes the launch lists that sdsm_batch_upload put on the device: a launch with the stale
     tables is an argument error, not undefined behaviour.  Also: per-candidate log files of compute_objects."""
