@@ -8,7 +8,7 @@ import torch
 from superdsm_amd import config, engine, globalenergymin, testing
 
 wl = sys.argv[1] if len(sys.argv) > 1 else 'bbbc039_like'
-scene = testing.make_scene(wl, max_size=3)
+scene = testing.make_scene(wl, max_size=3, layout_index=int(os.environ.get('LAYOUT', 0)))      # LAYOUT=k: the k-th BBBC039-like layout
 stage = globalenergymin.GlobalEnergyMinimization()
 gem = {'beta': float(sys.argv[2]) if len(sys.argv) > 2 else 150.0, 'pruning': 'isbi24'}
 if len(sys.argv) > 3:
