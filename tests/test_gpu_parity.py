@@ -1383,6 +1383,16 @@ def test_callable_dsm_init_starts_the_deformable_solve_where_the_caller_says(gpu
     assert solved.sum() >= 30 and called == r0['n_deform'][solved].tolist() and [s is not None for s in start] == solved.tolist()
     with pytest.raises(_capi.SdsmError, match='elliptical'):                # a plan that solves the elliptical model first has no use for starting points
         engine.Batch(img, fps, cfg).set_start(start)
+    # the same for regions whose rows of G~ a second kernel builds and that workgroup groups solve (the counts come from the first setup kernel alone)
+    big = testing.make_scene('gowt1_like', max_size=2)
+    bimg = engine.DeviceImage(big['y'], None, big['atoms'], big['dsm_cfg']['background_margin'])
+    g0 = engine.Batch(bimg, big['footprints'], dict(big['dsm_cfg'], init=None))
+    g0.launch()
+    g1 = engine.Batch(bimg, big['footprints'], dict(big['dsm_cfg'], init=zeros))
+    objects._starting_points(g1, dict(big['dsm_cfg'], init=zeros))
+    g1.launch()
+    rg = g0.records()
+    assert rg.tobytes() == g1.records().tobytes() and rg['n_pixels'].max() > 40000 and rg['n_deform'].max() > 128
     # a start of its own: a circle around the image centre and small alternating deformations
     def circle(m):
         xi = 0.01 * (-1.0) ** np.arange(m)
