@@ -503,3 +503,18 @@ def test_disk_morphology_from_the_definition():
                                 ero[y, x] = False
             np.testing.assert_array_equal(_morph.binary_dilation(img, fp), dil)
             np.testing.assert_array_equal(_morph.binary_erosion(img, fp), ero)
+
+
+def test_dsm_init_maps_to_the_solver_protocol():
+    """dsm/init (objects.py:384-393): 'elliptical' solves the elliptical model first; anything else -- None, or a callable whose return value is the
+    starting point (handed over by sdsm_plan_set_start) -- starts the DSM solve directly; the approximation knobs of the CPU implementation are checked as the reference checks them."""
+    from superdsm_amd import _capi, objects
+    assert _capi.make_config(dict(init='elliptical')).init_elliptical == 1 and _capi.make_config({}).init_elliptical == 1
+    assert _capi.make_config(dict(init=None)).init_elliptical == 0
+    assert _capi.make_config(dict(init=lambda m: np.zeros(6 + m))).init_elliptical == 0
+    cfg = objects._clean_cfg(dict(init=len, hessian_sparsity_tol=1e-3, cachesize=1, scale=1000))
+    assert cfg['init'] is len and 'hessian_sparsity_tol' not in cfg and 'cachesize' not in cfg
+    with pytest.raises(NotImplementedError):
+        objects._clean_cfg(dict(sparsity_tol=1e-3))
+    with pytest.raises(AssertionError):
+        objects._clean_cfg(dict(hessian_sparsity_tol=-1.0))
