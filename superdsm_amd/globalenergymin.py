@@ -8,6 +8,7 @@ generation / pruning logic is host-side bookkeeping and is restated here; every 
 batch.
 """
 import gc
+import math
 import os
 import sys
 import threading
@@ -88,7 +89,7 @@ def _generation_log_dir(log_root_dir, generation_number):
 
 
 def _within_seed_distance(footprint, new_atom, adjacencies, max_seed_distance):
-    if np.isinf(max_seed_distance):
+    if math.isinf(max_seed_distance):
         return True
     seed = np.asarray(adjacencies.get_seed(new_atom))
     return all(np.linalg.norm(np.asarray(adjacencies.get_seed(a)) - seed) <= max_seed_distance for a in footprint)
@@ -102,9 +103,10 @@ def _expand(footprint, adjacencies, max_seed_distance, skip_last):
     neighbours = set()
     for atom in footprint:
         neighbours |= adjacencies[atom] - footprint
-    unbounded = np.isinf(max_seed_distance)
-    return cluster, tuple((frozenset(footprint | {new_atom}), new_atom) for new_atom in neighbours
-                          if unbounded or _within_seed_distance(footprint, new_atom, adjacencies, max_seed_distance))
+    if math.isinf(max_seed_distance):                        # (math, not np.isinf -- 0.6 us on a scalar --, and a list instead of a generator: a third of this function)
+        return cluster, tuple([(frozenset(footprint | {new_atom}), new_atom) for new_atom in neighbours])
+    return cluster, tuple([(frozenset(footprint | {new_atom}), new_atom) for new_atom in neighbours
+                           if _within_seed_distance(footprint, new_atom, adjacencies, max_seed_distance)])
 
 
 def _iterate_generation(previous_generation, adjacencies, max_seed_distance, get_footprint=lambda item: item,
